@@ -1,0 +1,150 @@
+/*
+ * vivim_hip.h -- C ABI of libvivim_hip.so: the MI355X (gfx950) drop-in for the two CUDA extension
+ * modules on Vivim's Temporal-Mamba hot path.
+ *
+ * Each entry point replaces one function the reference binds with pybind11 (all citations are
+ * file:line under /root/reference):
+ *
+ *   vivim_selective_scan_fwd  <- selective_scan_cuda.fwd   mamba/csrc/selective_scan/selective_scan.cpp:226-336
+ *                                params struct SSMParamsBase mamba/csrc/selective_scan/selective_scan.h:26-69
+ *   vivim_selective_scan_bwd  <- selective_scan_cuda.bwd   mamba/csrc/selective_scan/selective_scan.cpp:338-492
+ *                                params struct SSMParamsBwd  mamba/csrc/selective_scan/selective_scan.h:71-101
+ *   vivim_causal_conv1d_fwd   <- causal_conv1d_cuda.causal_conv1d_fwd  causal-conv1d/csrc/causal_conv1d.cpp:130-189
+ *                                params struct ConvParamsBase causal-conv1d/csrc/causal_conv1d.h:9-35
+ *   vivim_causal_conv1d_bwd   <- causal_conv1d_cuda.causal_conv1d_bwd  causal-conv1d/csrc/causal_conv1d.cpp:191-268
+ *                                params struct ConvParamsBwd  causal-conv1d/csrc/causal_conv1d.h:37-52
+ *
+ * Contract (same as the reference bindings after their ATen part):
+ *   - every pointer is a DEVICE pointer on the current device; strides are in ELEMENTS; the token
+ *     (seqlen) axis of every activation tensor has unit stride; batch / channel strides are free
+ *     (Vivim passes halves of `xz`, strides (L, B*L, 1) -- mamba_simple.py:204-208).
+ *   - the call only enqueues kernels on `stream` (a hipStream_t, NULL = default stream): it never
+ *     synchronises, allocates or frees, and keeps no state between calls (re-entrant).
+ *   - outputs are caller-allocated.  Accumulated outputs (dA, dB, dC, dD, ddelta_bias, dweight,
+ *     dbias) are float32 and MUST be zero-filled by the caller before the call, exactly as the
+ *     reference binding does (selective_scan.cpp:458-466, causal_conv1d.cpp:247-249).
+ *   - returns 0 on success; otherwise a VIVIM_ERR_* code, and vivim_last_error() returns a
+ *     thread-local message naming the failed check (the reference raises RuntimeError there).
+ *
+ * Differences from the reference structs, on purpose: strides are int64 (a 288 GB HBM3E part holds
+ * tensors past 2^32 elements; the reference uses uint32, selective_scan.h:27); the input dtype is an
+ * explicit enum instead of a C++ template dispatch; `x` (scan checkpoints) has OUR chunk length,
+ * vivim_scan_chunk_len(), instead of the reference's fixed 2048 (selective_scan.cpp:307).
+ */
+#ifndef VIVIM_HIP_H
+#define VIVIM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VIVIM_ABI_VERSION 1
+
+typedef enum { VIVIM_F32 = 0, VIVIM_F16 = 1, VIVIM_BF16 = 2 } vivim_dtype_t;
+
+enum {
+    VIVIM_OK = 0,
+    VIVIM_ERR_INVALID = 1,      /* failed shape / stride / pointer check */
+    VIVIM_ERR_UNSUPPORTED = 2,  /* valid in the reference but not built here (see message) */
+    VIVIM_ERR_LAUNCH = 3        /* hipGetLastError() after the launch */
+};
+
+/* ---- selective scan, forward (selective_scan.h:26-69) --------------------------------------- */
+typedef struct {
+    int32_t batch, dim, seqlen, dstate, n_groups;
+    int32_t itype;              /* vivim_dtype_t of u, delta, z, out, out_z and of variable B / C */
+    int32_t is_variable_B;      /* B is (batch, n_groups, dstate, seqlen) itype; else (dim, dstate) f32 */
+    int32_t is_variable_C;
+    int32_t delta_softplus;
+    int32_t _pad0;
+    int64_t u_batch_stride, u_d_stride;
+    int64_t delta_batch_stride, delta_d_stride;
+    int64_t z_batch_stride, z_d_stride;
+    int64_t out_batch_stride, out_d_stride;
+    int64_t out_z_batch_stride, out_z_d_stride;
+    int64_t A_d_stride, A_dstate_stride;
+    int64_t B_batch_stride, B_group_stride, B_dstate_stride;   /* constant B: batch/group stride unused, */
+    int64_t C_batch_stride, C_group_stride, C_dstate_stride;   /* B_d_stride == B_group_stride slot     */
+    const void *u, *delta;      /* (batch, dim, seqlen) itype */
+    const void *A;              /* (dim, dstate) f32 */
+    const void *B, *C;
+    const void *D;              /* (dim) f32 or NULL */
+    const void *delta_bias;     /* (dim) f32 or NULL */
+    const void *z;              /* (batch, dim, seqlen) itype or NULL */
+    void *out;                  /* (batch, dim, seqlen) itype: y + D*u, before gating */
+    void *out_z;                /* out * silu(z); required iff z != NULL */
+    void *x;                    /* (batch, dim, n_chunks, dstate) f32 contiguous: state after each chunk of
+                                   vivim_scan_chunk_len() tokens; x[:, :, -1, :] is the final state
+                                   (the reference's x[:, :, -1, 1::2], selective_scan_interface.py:40) */
+} vivim_ssm_fwd_params;
+
+/* ---- selective scan, backward (selective_scan.h:71-101) ------------------------------------- */
+typedef struct {
+    vivim_ssm_fwd_params f;     /* forward tensors; f.out = SAVED forward `out` (needed iff z != NULL);
+                                   f.out_z = optional recomputed out_z destination (may be NULL);
+                                   f.x = forward checkpoints (required when seqlen > chunk_len) */
+    int64_t dout_batch_stride, dout_d_stride;
+    int64_t du_batch_stride, du_d_stride;
+    int64_t ddelta_batch_stride, ddelta_d_stride;
+    int64_t dz_batch_stride, dz_d_stride;
+    int64_t dA_d_stride, dA_dstate_stride;
+    int64_t dB_batch_stride, dB_group_stride, dB_dstate_stride;
+    int64_t dC_batch_stride, dC_group_stride, dC_dstate_stride;
+    const void *dout;           /* (batch, dim, seqlen) itype */
+    void *du, *ddelta;          /* itype */
+    void *dz;                   /* itype; required iff z != NULL (may alias a caller view of dxz) */
+    void *dA;                   /* (dim, dstate) f32, pre-zeroed */
+    void *dB, *dC;              /* f32, pre-zeroed: (batch, n_groups, dstate, seqlen) if variable else (dim, dstate) */
+    void *dD;                   /* (dim) f32 pre-zeroed, or NULL iff D == NULL */
+    void *ddelta_bias;          /* (dim) f32 pre-zeroed, or NULL iff delta_bias == NULL */
+} vivim_ssm_bwd_params;
+
+/* ---- causal depthwise conv1d (causal_conv1d.h:9-52) ------------------------------------------ */
+typedef struct {
+    int32_t batch, dim, seqlen, width;   /* width in [2, 4] (causal_conv1d.cpp:157) */
+    int32_t itype;                       /* dtype of x, out, dout, dx */
+    int32_t wtype;                       /* dtype of weight and bias */
+    int32_t silu_activation;
+    int32_t _pad0;
+    int64_t x_batch_stride, x_c_stride, x_l_stride;         /* x_l_stride must be 1 (channel-first) */
+    int64_t out_batch_stride, out_c_stride, out_l_stride;
+    int64_t weight_c_stride, weight_width_stride;
+    const void *x;              /* (batch, dim, seqlen) */
+    const void *weight;         /* (dim, width) */
+    const void *bias;           /* (dim) or NULL */
+    void *out;                  /* forward output; unused by the backward */
+} vivim_conv_fwd_params;
+
+typedef struct {
+    vivim_conv_fwd_params f;
+    int64_t dout_batch_stride, dout_c_stride, dout_l_stride;
+    int64_t dx_batch_stride, dx_c_stride, dx_l_stride;
+    int64_t dweight_c_stride, dweight_width_stride;
+    const void *dout;
+    void *dx;                   /* itype, may be a strided caller view (causal_conv1d.cpp:232-238) */
+    void *dweight;              /* (dim, width) f32 pre-zeroed */
+    void *dbias;                /* (dim) f32 pre-zeroed, or NULL iff bias == NULL */
+} vivim_conv_bwd_params;
+
+int vivim_abi_version(void);
+const char *vivim_last_error(void);
+
+/* sizeof() of a params struct as this library was compiled, so a foreign-language binding can assert
+ * its own layout: which = 0 ssm_fwd, 1 ssm_bwd, 2 conv_fwd, 3 conv_bwd; 0 for anything else. */
+size_t vivim_sizeof(int which);
+
+/* Tokens per checkpoint row of `x` for an input dtype; n_chunks = ceil(seqlen / chunk_len). */
+int vivim_scan_chunk_len(int itype);
+
+int vivim_selective_scan_fwd(const vivim_ssm_fwd_params *p, void *stream);
+int vivim_selective_scan_bwd(const vivim_ssm_bwd_params *p, void *stream);
+int vivim_causal_conv1d_fwd(const vivim_conv_fwd_params *p, void *stream);
+int vivim_causal_conv1d_bwd(const vivim_conv_bwd_params *p, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIVIM_HIP_H */

@@ -1,0 +1,83 @@
+"""CPU: the C-ABI shared library loads without a GPU, exports every symbol include/vivim_hip.h declares,
+agrees with the ctypes struct layouts, and rejects bad params before any launch."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from vivim_amd import _lib
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "vivim_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vivim_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported():
+    L = _lib.lib()
+    names = _declared_functions()
+    assert set(_lib.EXPORTS) == set(names)
+    for n in names:
+        assert hasattr(L, n), n
+
+
+def test_struct_layouts_match():
+    L = _lib.lib()
+    for which, st in enumerate((_lib.SsmFwdParams, _lib.SsmBwdParams, _lib.ConvFwdParams, _lib.ConvBwdParams)):
+        assert L.vivim_sizeof(which) == ctypes.sizeof(st)
+    assert L.vivim_sizeof(99) == 0
+    assert L.vivim_abi_version() == 1
+    assert L.vivim_scan_chunk_len(_lib.F32) > 0 and L.vivim_scan_chunk_len(_lib.BF16) % 64 == 0
+
+
+def test_rejects_before_launch():
+    """Invalid params are refused on the host (no GPU needed): null struct, bad width, bad dtype."""
+    L = _lib.lib()
+    assert L.vivim_selective_scan_fwd(None, None) == 1
+    assert b"check failed" in L.vivim_last_error()
+    p = _lib.ConvFwdParams()
+    p.batch, p.dim, p.seqlen, p.width = 1, 4, 8, 5
+    p.x, p.weight, p.out = 1, 1, 1
+    p.x_l_stride = p.out_l_stride = 1
+    assert L.vivim_causal_conv1d_fwd(ctypes.byref(p), None) == 1
+    assert b"width between 2 and 4" in L.vivim_last_error()
+    p.width, p.itype = 4, 7
+    assert L.vivim_causal_conv1d_fwd(ctypes.byref(p), None) == 1
+    p.itype, p.x_l_stride = 0, 4
+    assert L.vivim_causal_conv1d_fwd(ctypes.byref(p), None) == 2          # channel-last: unsupported
+    s = _lib.SsmFwdParams()
+    s.batch = s.dim = s.seqlen = s.n_groups = 1
+    s.dstate = 300
+    assert L.vivim_selective_scan_fwd(ctypes.byref(s), None) == 1
+
+
+def test_call_raises_runtime_error():
+    with pytest.raises(RuntimeError, match="check failed"):
+        _lib.call("vivim_selective_scan_fwd", _lib.SsmFwdParams(), 0)
+
+
+def test_python_surface_imports_without_gpu():
+    import causal_conv1d  # noqa: F401
+    import causal_conv1d_cuda
+    import mamba_ssm
+    import selective_scan_cuda
+    from modeling.vivim import MambaLayer, Vivim, mamba_block  # noqa: F401
+    assert callable(selective_scan_cuda.fwd) and callable(selective_scan_cuda.bwd)
+    assert callable(causal_conv1d_cuda.causal_conv1d_fwd) and callable(causal_conv1d_cuda.causal_conv1d_bwd)
+    assert hasattr(mamba_ssm, "Mamba") and hasattr(mamba_ssm, "selective_scan_fn")
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under vivim_amd/ (or the alias packages) may reference it."""
+    bad = []
+    for top in ("vivim_amd", "mamba_ssm", "causal_conv1d", "modeling"):
+        for dp, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".cuh", ".h")):
+                    src = open(os.path.join(dp, f)).read()
+                    if re.search(r"^\s*(from|import)\s+oracle\b|ssm_oracle|ref_torch", src, flags=re.M):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad

@@ -1,0 +1,428 @@
+"""GPU parity tests (pytest -m gpu): the HIP kernels, called through the C ABI by the drop-in modules
+`selective_scan_cuda` / `causal_conv1d_cuda`, against (1) the committed golden vectors produced by the
+reference's own refs, (2) the CPU oracle on seeded inputs, (3) size-independent properties at
+BASELINE.json's full sizes.
+
+Tolerance (BASELINE.json north_star): relative error ||a-b|| / ||b|| <= 1e-3 against the reference math,
+for fp32 I/O directly and for bf16/fp16 I/O after rounding the oracle's result to the I/O dtype.  The
+outer bounds the reference itself uses are rtol/atol 6e-4/2e-3 (fp32), 3e-3/5e-3 (fp16), 3e-2/5e-2 (bf16)
+(mamba/tests/ops/test_selective_scan.py:45-51) -- ours is tighter.
+"""
+import pytest
+import torch
+
+from conftest import DT, golden_names, load_golden, rel_err
+from oracle import cpu_oracle
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3
+TOL_FP32 = 2e-5         # what fp32 I/O actually has to meet here (fp32 state vs fp64 oracle)
+
+
+def _tol(dtype):
+    return TOL_FP32 if dtype == torch.float32 else TOL
+
+
+def _round(t, dtype):
+    return t.to(dtype).float()
+
+
+@pytest.fixture(scope="module")
+def ops(cuda):
+    import causal_conv1d_cuda
+    import selective_scan_cuda
+    return selective_scan_cuda, causal_conv1d_cuda
+
+
+def _opt(g, k, dev, dtype=None):
+    if k not in g:
+        return None
+    t = g[k].to(dev)
+    return t.to(dtype) if dtype is not None else t
+
+
+# ------------------------------------------------------------------ causal conv1d
+
+@pytest.mark.parametrize("name", golden_names("conv_"))
+def test_conv_golden(name, cuda, ops):
+    _, cc = ops
+    g = load_golden(name)
+    dt = DT[g["dtype"]]
+    silu = bool(g["meta"][4])
+    x, dout = g["x"].to(cuda, dt), g["dout"].to(cuda, dt)
+    w, b = g["weight"].to(cuda), _opt(g, "bias", cuda)
+    out = cc.causal_conv1d_fwd(x, w, b, silu)
+    assert out.dtype == dt and out.shape == x.shape
+    assert rel_err(out.float(), g["out"]) < _tol(dt)
+    dx, dw, db = cc.causal_conv1d_bwd(x, w, b, dout, None, silu)
+    assert rel_err(dx.float(), g["dx"]) < max(_tol(dt), 5e-5) * (3 if dt != torch.float32 else 1)
+    assert rel_err(dw, g["dweight"]) < max(_tol(dt), 5e-5) * (3 if dt != torch.float32 else 1)
+    if b is not None:
+        assert rel_err(db, g["dbias"]) < max(_tol(dt), 5e-5) * (3 if dt != torch.float32 else 1)
+    else:
+        assert db is None
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("width", [2, 3, 4])
+@pytest.mark.parametrize("seqlen", [1, 2, 8, 151, 512, 1024, 1134, 2049, 4100])
+def test_conv_vs_oracle(dtype, width, seqlen, cuda, ops):
+    """Shapes / odd lengths of causal-conv1d/tests/test_causal_conv1d.py:14-46, including the
+    non-contiguous batch stride (x is a channel slice of a larger tensor)."""
+    _, cc = ops
+    gen = torch.Generator().manual_seed(seqlen * 7 + width)
+    batch, dim = 2, 96
+    big = torch.randn(batch, dim + 32, seqlen, generator=gen).to(dtype).to(cuda)
+    x = big[:, :dim]                                  # batch stride (dim+32)*L
+    w = torch.randn(dim, width, generator=gen).to(cuda)
+    b = torch.randn(dim, generator=gen).to(cuda)
+    dout = torch.randn(batch, dim, seqlen, generator=gen).to(dtype).to(cuda)
+    for silu, bias in ((True, b), (False, None)):
+        out = cc.causal_conv1d_fwd(x, w, bias, silu)
+        ref = cpu_oracle.causal_conv1d_fwd(x, w, bias, silu)
+        assert rel_err(out.float(), _round(ref, dtype)) < _tol(dtype), (silu,)
+        dx, dw, db = cc.causal_conv1d_bwd(x, w, bias, dout, None, silu)
+        rdx, rdw, rdb = cpu_oracle.causal_conv1d_bwd(x, w, bias, dout, silu)
+        assert rel_err(dx.float(), _round(rdx, dtype)) < _tol(dtype)
+        assert rel_err(dw, rdw) < 1e-4
+        if bias is not None:
+            assert rel_err(db, rdb) < 1e-4
+
+
+def test_conv_xz_layout_and_prealloc_dx(cuda, ops):
+    """The layout Vivim actually passes: x = first half of xz with strides (L, B*L, 1); dx written into a
+    caller-owned half of dxz (selective_scan_interface.py:244-245, 281-283)."""
+    _, cc = ops
+    gen = torch.Generator().manual_seed(11)
+    B, D, L = 3, 64, 1280
+    xz = torch.randn(2 * D, B, L, generator=gen).to(torch.bfloat16).to(cuda).transpose(0, 1)
+    x = xz[:, :D]
+    assert x.stride() == (L, B * L, 1)
+    w = torch.randn(D, 4, generator=gen).to(cuda)
+    b = torch.randn(D, generator=gen).to(cuda)
+    out = cc.causal_conv1d_fwd(x, w, b, True)
+    assert out.stride() == x.stride()
+    assert rel_err(out.float(), _round(cpu_oracle.causal_conv1d_fwd(x, w, b, True), torch.bfloat16)) < TOL
+    dxz = torch.full_like(xz, 7.0)
+    dx_view = dxz[:, :D]
+    dout = torch.randn(B, D, L, generator=gen).to(torch.bfloat16).to(cuda)
+    dx, dw, db = cc.causal_conv1d_bwd(x, w, b, dout, dx_view, True)
+    assert dx.data_ptr() == dx_view.data_ptr()
+    rdx, _, _ = cpu_oracle.causal_conv1d_bwd(x, w, b, dout, True)
+    assert rel_err(dxz[:, :D].float(), _round(rdx, torch.bfloat16)) < TOL
+    assert bool((dxz[:, D:] == 7.0).all())           # the z half was not touched
+
+
+def test_conv_deterministic_outputs(cuda, ops):
+    """Spirit of test_causal_conv1d_race_condition (test_causal_conv1d.py:117-173): out/dx bit-stable
+    across repeats, atomically reduced dw/db within 1e-4."""
+    _, cc = ops
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 128, 2048, generator=gen).to(torch.bfloat16).to(cuda)
+    w, b = torch.randn(128, 4, generator=gen).to(cuda), torch.randn(128, generator=gen).to(cuda)
+    dout = torch.randn(2, 128, 2048, generator=gen).to(torch.bfloat16).to(cuda)
+    out0 = cc.causal_conv1d_fwd(x, w, b, True)
+    dx0, dw0, db0 = cc.causal_conv1d_bwd(x, w, b, dout, None, True)
+    for _ in range(50):
+        out = cc.causal_conv1d_fwd(x, w, b, True)
+        dx, dw, db = cc.causal_conv1d_bwd(x, w, b, dout, None, True)
+        assert torch.equal(out, out0) and torch.equal(dx, dx0)
+        assert torch.allclose(dw, dw0, rtol=1e-4, atol=1e-4) and torch.allclose(db, db0, rtol=1e-4, atol=1e-4)
+
+
+def test_conv_errors(cuda, ops):
+    _, cc = ops
+    from causal_conv1d import causal_conv1d_fn
+    x = torch.randn(2, 8, 16, device=cuda)
+    with pytest.raises(RuntimeError):
+        cc.causal_conv1d_fwd(x, torch.randn(8, 5, device=cuda), None, False)       # width 5
+    with pytest.raises(RuntimeError):
+        cc.causal_conv1d_fwd(x, torch.randn(7, 4, device=cuda), None, False)       # dim mismatch
+    with pytest.raises(RuntimeError):
+        cc.causal_conv1d_fwd(x.double(), torch.randn(8, 4, device=cuda), None, False)
+    with pytest.raises(NotImplementedError):
+        causal_conv1d_fn(x, torch.randn(8, 4, device=cuda), None, "relu")
+
+
+# ------------------------------------------------------------------ selective scan
+
+def _scan_case_tensors(g, dev):
+    dt = DT[g["dtype"]]
+    vB, vC = bool(g["meta"][5]), bool(g["meta"][6])
+    return dict(
+        u=g["u"].to(dev, dt), delta=g["delta"].to(dev, dt), A=g["A"].to(dev),
+        B=g["B"].to(dev, dt if vB else torch.float32), C=g["C"].to(dev, dt if vC else torch.float32),
+        D=_opt(g, "D", dev), z=_opt(g, "z", dev, dt), delta_bias=_opt(g, "delta_bias", dev),
+        dout=g["dout"].to(dev, dt), softplus=bool(g["meta"][10]), dtype=dt)
+
+
+def _dz_from_saved_out(dout, out, z):
+    """The kernel contract for dz uses the SAVED (rounded) out: bwd_kernel.cuh:186-191."""
+    zf, sg = z.float(), torch.sigmoid(z.float())
+    return dout.float() * out.float() * sg * (1 + zf * (1 - sg))
+
+
+def _check_scan(t, ss, expect_fwd=None, expect_bwd=None, tol=None):
+    dt = t["dtype"]
+    tol = tol or _tol(dt)
+    res = ss.fwd(t["u"], t["delta"], t["A"], t["B"], t["C"], t["D"], t["z"], t["delta_bias"], t["softplus"])
+    out, x = res[0], res[1]
+    out_z = res[2] if t["z"] is not None else None
+    if expect_fwd is None:
+        r_out, r_out_z, r_last = cpu_oracle.selective_scan_fwd(t["u"], t["delta"], t["A"], t["B"], t["C"], t["D"],
+                                                               t["z"], t["delta_bias"], t["softplus"])
+    else:
+        r_out, r_out_z, r_last = expect_fwd
+    if r_out is not None:
+        assert rel_err(out.float(), _round(r_out, dt)) < tol
+    if out_z is not None:
+        assert rel_err(out_z.float(), _round(r_out_z, dt)) < tol
+    assert rel_err(x[:, :, -1, :], r_last) < max(tol, 1e-5)
+    dz_buf = torch.empty_like(t["z"]) if t["z"] is not None else None
+    grads = ss.bwd(t["u"], t["delta"], t["A"], t["B"], t["C"], t["D"], t["z"], t["delta_bias"], t["dout"], x,
+                   out if t["z"] is not None else None, dz_buf, t["softplus"], False)
+    du, ddelta, dA, dB, dC, dD, dbias = grads[:7]
+    r = expect_bwd or cpu_oracle.selective_scan_bwd(t["u"], t["delta"], t["A"], t["B"], t["C"], t["D"], t["z"],
+                                                    t["delta_bias"], t["dout"], t["softplus"])
+    lo = dt != torch.float32
+    gt = tol * (4 if lo else 5)       # low-precision grads are products of rounded inputs; fp32: 1e-4
+    assert rel_err(du.float(), _round(r["du"], dt)) < gt, "du"
+    assert rel_err(ddelta.float(), _round(r["ddelta"], dt)) < gt, "ddelta"
+    assert rel_err(dA, r["dA"]) < gt, "dA"
+    assert rel_err(dB.float(), _round(r["dB"], dB.dtype)) < gt, "dB"
+    assert rel_err(dC.float(), _round(r["dC"], dC.dtype)) < gt, "dC"
+    if t["D"] is not None:
+        assert rel_err(dD, r["dD"]) < gt, "dD"
+    if t["delta_bias"] is not None:
+        assert rel_err(dbias, r["ddelta_bias"]) < gt, "ddelta_bias"
+    if t["z"] is not None:
+        dz = grads[7]
+        assert dz.data_ptr() == dz_buf.data_ptr()
+        if lo:
+            assert rel_err(dz.float(), _round(_dz_from_saved_out(t["dout"], out, t["z"]), dt)) < gt, "dz"
+        else:
+            assert rel_err(dz.float(), r["dz"]) < gt, "dz"
+
+
+@pytest.mark.parametrize("name", golden_names("scan_"))
+def test_scan_golden(name, cuda, ops):
+    ss, _ = ops
+    g = load_golden(name)
+    t = _scan_case_tensors(g, cuda)
+    has_z = "z" in g
+    exp_f = (None if has_z else g["out"], g["out"] if has_z else None, g["last_state"])
+    exp_b = {k: g.get(k) for k in ("du", "ddelta", "dA", "dB", "dC", "dD", "dz", "ddelta_bias")}
+    _check_scan(t, ss, exp_f, exp_b, tol=_tol(t["dtype"]) if t["dtype"] == torch.float32 else 2e-3)
+
+
+def _rand_scan(gen, batch, dim, N, L, G, dtype, dev, has_z=True, has_D=True, has_bias=True, softplus=True,
+               strided=False, init="test"):
+    if init == "test":      # test_selective_scan.py:58-88
+        A = -0.5 * torch.rand(dim, N, generator=gen)
+        delta = 0.5 * torch.rand(batch, dim, L, generator=gen)
+        bias = 0.5 * torch.rand(dim, generator=gen)
+    else:                   # module init, mamba_simple.py:99-117
+        A = -torch.arange(1, N + 1, dtype=torch.float32).repeat(dim, 1)
+        delta = 0.2 * torch.randn(batch, dim, L, generator=gen)
+        dtv = torch.exp(torch.rand(dim, generator=gen) * 4.605 - 6.908)
+        bias = dtv + torch.log(-torch.expm1(-dtv))
+
+    def act(*shape):
+        t = torch.randn(*shape, generator=gen).to(dtype)
+        if strided and len(shape) == 3:              # (L, B*L, 1) strides: a (D, B, L) buffer viewed as (B, D, L)
+            return t.transpose(0, 1).contiguous().to(dev).transpose(0, 1)
+        return t.to(dev)
+
+    u, dout = act(batch, dim, L), act(batch, dim, L)
+    delta = delta.to(dtype)
+    delta = delta.transpose(0, 1).contiguous().to(dev).transpose(0, 1) if strided else delta.to(dev)
+    return dict(u=u, delta=delta, A=A.to(dev), B=act(batch, G, N, L), C=act(batch, G, N, L),
+                D=torch.randn(dim, generator=gen).to(dev) if has_D else None,
+                z=act(batch, dim, L) if has_z else None,
+                delta_bias=bias.to(dev) if has_bias else None, dout=dout, softplus=softplus, dtype=dtype)
+
+
+@pytest.mark.parametrize("seqlen", [1, 3, 64, 128, 151, 255, 256, 257, 320, 372, 784, 1024, 1134, 2048, 2049, 4096])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_scan_vs_oracle_lengths(seqlen, dtype, cuda, ops):
+    """Sequence lengths of test_selective_scan.py:23-33 (+ our chunk edges 255/256/257)."""
+    ss, _ = ops
+    gen = torch.Generator().manual_seed(1000 + seqlen)
+    _check_scan(_rand_scan(gen, 2, 4, 8, seqlen, 1, dtype, cuda), ss)
+
+
+@pytest.mark.parametrize("dim,N,G", [(4, 1, 1), (96, 16, 1), (130, 16, 2), (6, 64, 1), (5, 16, 1), (8, 200, 2)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_scan_vs_oracle_shapes(dim, N, G, dtype, cuda, ops):
+    ss, _ = ops
+    gen = torch.Generator().manual_seed(dim * 31 + N)
+    _check_scan(_rand_scan(gen, 3, dim, N, 333, G, dtype, cuda, init="module"), ss)
+
+
+@pytest.mark.parametrize("has_z,has_D,has_bias,softplus",
+                         [(False, False, False, False), (True, False, True, False), (False, True, False, True),
+                          (True, True, False, True)])
+def test_scan_optional_arguments(has_z, has_D, has_bias, softplus, cuda, ops):
+    """Flag grid of test_selective_scan.py:17-39 (each optional input off/on)."""
+    ss, _ = ops
+    gen = torch.Generator().manual_seed(77)
+    _check_scan(_rand_scan(gen, 2, 12, 16, 700, 1, torch.float32, cuda, has_z, has_D, has_bias, softplus), ss)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_scan_vivim_strides(dtype, cuda, ops):
+    """(L, B*L, 1)-strided u / delta / z / dout as produced by mamba_simple.py:204-208; out inherits
+    delta's strides (selective_scan.cpp:311)."""
+    ss, _ = ops
+    gen = torch.Generator().manual_seed(3)
+    t = _rand_scan(gen, 3, 64, 16, 1280, 1, dtype, cuda, strided=True, init="module")
+    assert t["u"].stride() == (1280, 3 * 1280, 1)
+    out = ss.fwd(t["u"], t["delta"], t["A"], t["B"], t["C"], t["D"], t["z"], t["delta_bias"], True)[0]
+    assert out.stride() == t["delta"].stride()
+    _check_scan(t, ss)
+
+
+def test_scan_large_delta_softplus_threshold(cuda, ops):
+    """delta + bias > 20 takes the identity branch of softplus in fwd and bwd (fwd_kernel.cuh:155, bwd:447)."""
+    ss, _ = ops
+    gen = torch.Generator().manual_seed(9)
+    t = _rand_scan(gen, 1, 8, 8, 300, 1, torch.float32, cuda)
+    t["delta"] = t["delta"] * 60.0 - 5.0            # spans both sides of the threshold
+    t["A"] = t["A"] * 0.01
+    _check_scan(t, ss, tol=1e-4)
+
+
+def test_scan_constant_BC(cuda, ops):
+    ss, _ = ops
+    t = _scan_case_tensors(load_golden("scan_constBC"), cuda)
+    _check_scan(t, ss)
+
+
+def test_scan_errors(cuda, ops):
+    ss, _ = ops
+    gen = torch.Generator().manual_seed(1)
+    t = _rand_scan(gen, 2, 4, 8, 64, 1, torch.float32, cuda)
+    args = [t["u"], t["delta"], t["A"], t["B"], t["C"], t["D"], t["z"], t["delta_bias"], True]
+    with pytest.raises(RuntimeError):
+        ss.fwd(*[a.double() if i == 0 else a for i, a in enumerate(args)])           # unsupported dtype
+    with pytest.raises(RuntimeError):
+        ss.fwd(args[0], args[1][:, :, :32], *args[2:])                                # shape mismatch
+    with pytest.raises(RuntimeError):
+        ss.fwd(args[0].transpose(1, 2).contiguous().transpose(1, 2), *args[1:])       # stride(-1) != 1
+    with pytest.raises(RuntimeError):
+        ss.fwd(args[0], args[1], torch.randn(4, 300, device=cuda), torch.randn(2, 1, 300, 64, device=cuda),
+               torch.randn(2, 1, 300, 64, device=cuda), None, None, None, False)      # dstate > 256
+    with pytest.raises(RuntimeError):
+        ss.fwd(args[0].cpu(), *args[1:])                                              # not on the GPU
+
+
+def test_selective_scan_fn_autograd(cuda):
+    """Public op: selective_scan_fn with 3-D B/C (squeeze path), return_last_state, autograd
+    (selective_scan_interface.py:14-83) -- the pattern of test_selective_scan.py:89-149."""
+    from mamba_ssm import selective_scan_fn
+    g = load_golden("scan_tss_l128")
+    t = _scan_case_tensors(g, cuda)
+    leaves = {k: t[k].clone().requires_grad_(True) for k in ("u", "delta", "A", "D", "z", "delta_bias")}
+    B3 = t["B"].squeeze(1).clone().requires_grad_(True)
+    C3 = t["C"].squeeze(1).clone().requires_grad_(True)
+    out, last = selective_scan_fn(leaves["u"], leaves["delta"], leaves["A"], B3, C3, leaves["D"], leaves["z"],
+                                  leaves["delta_bias"], delta_softplus=True, return_last_state=True)
+    assert rel_err(out, g["out"]) < TOL_FP32 and rel_err(last, g["last_state"]) < TOL_FP32
+    out.backward(t["dout"])
+    for k, gk in (("u", "du"), ("delta", "ddelta"), ("A", "dA"), ("D", "dD"), ("z", "dz"),
+                  ("delta_bias", "ddelta_bias")):
+        assert rel_err(leaves[k].grad, g[gk]) < 1e-4, k
+    assert B3.grad.shape == B3.shape
+    assert rel_err(B3.grad, g["dB"].squeeze(1)) < 1e-4 and rel_err(C3.grad, g["dC"].squeeze(1)) < 1e-4
+
+
+# ------------------------------------------------------------------ full-size properties (BASELINE.json configs)
+
+FULL = [  # (config, batch, dim, N, L, dtype): stage-0 shapes of SURVEY.md section 8
+    ("cfg2_stage0", 3, 128, 16, 20480, torch.bfloat16),
+    ("cfg3_stage0", 8, 128, 16, 81920, torch.float32),
+    ("cfg5_stage0", 1, 256, 64, 32768, torch.bfloat16),
+    ("cfg2_stage3", 3, 1024, 16, 320, torch.bfloat16),
+]
+
+
+@pytest.mark.parametrize("cfg,batch,dim,N,L,dtype", FULL)
+def test_scan_full_size_properties(cfg, batch, dim, N, L, dtype, cuda, ops):
+    """At full size the CPU oracle is too slow for every channel, so:
+      (a) channels are independent given B/C -> the oracle is run on a 6-channel slice of the full-length
+          problem and must match those channels of the full GPU result (fwd + per-channel grads);
+      (b) causality: the first 1000 outputs do not change when every token after 1000 is perturbed;
+      (c) linearity in u (z=None, fixed delta): scan(u1 + u2) == scan(u1) + scan(u2);
+      (d) dB is linear in dout and sums over channels: checked against the oracle on a short prefix-free
+          problem by zeroing dout outside the 6-channel slice."""
+    ss, _ = ops
+    gen = torch.Generator().manual_seed(42)
+    t = _rand_scan(gen, batch, dim, N, L, 1, dtype, cuda, strided=True, init="module")
+    out, x, out_z = ss.fwd(t["u"], t["delta"], t["A"], t["B"], t["C"], t["D"], t["z"], t["delta_bias"], True)
+    sel = torch.tensor([0, 1, dim // 2, dim // 2 + 1, dim - 2, dim - 1], device=cuda)
+    b0 = batch - 1
+    sub = lambda a: a[b0:b0 + 1].index_select(1, sel)
+    r_out, r_out_z, r_last = cpu_oracle.selective_scan_fwd(
+        sub(t["u"]), sub(t["delta"]), t["A"][sel], t["B"][b0:b0 + 1], t["C"][b0:b0 + 1], t["D"][sel],
+        sub(t["z"]), t["delta_bias"][sel], True)
+    tol = _tol(dtype)
+    assert rel_err(sub(out).float(), _round(r_out, dtype)) < tol
+    assert rel_err(sub(out_z).float(), _round(r_out_z, dtype)) < tol
+    assert rel_err(x[b0, sel, -1, :], r_last[0]) < max(tol, 1e-4)
+    # (d) + per-channel grads: dout nonzero only on the slice
+    dout = torch.zeros_like(t["dout"])
+    dout[b0, sel] = t["dout"][b0, sel]
+    g = ss.bwd(t["u"], t["delta"], t["A"], t["B"], t["C"], t["D"], t["z"], t["delta_bias"], dout, x, out, None,
+               True, False)
+    r = cpu_oracle.selective_scan_bwd(sub(t["u"]), sub(t["delta"]), t["A"][sel], t["B"][b0:b0 + 1], t["C"][b0:b0 + 1],
+                                      t["D"][sel], sub(t["z"]), t["delta_bias"][sel], sub(dout), True)
+    gt = 5e-3 if dtype != torch.float32 else 2e-4
+    assert rel_err(sub(g[0]).float(), _round(r["du"], dtype)) < gt
+    assert rel_err(sub(g[1]).float(), _round(r["ddelta"], dtype)) < gt
+    assert rel_err(g[2][sel], r["dA"]) < gt
+    assert rel_err(g[3][b0:b0 + 1].float(), _round(r["dB"], dtype)) < gt
+    assert rel_err(g[4][b0:b0 + 1].float(), _round(r["dC"], dtype)) < gt
+    assert rel_err(g[5][sel], r["dD"]) < gt and rel_err(g[6][sel], r["ddelta_bias"]) < gt
+    others = torch.ones(dim, dtype=torch.bool, device=cuda)
+    others[sel] = False
+    assert float(g[0][b0][others].abs().max()) == 0.0          # zero dout rows give exactly zero du
+    if batch > 1:
+        assert float(g[3][:b0].abs().max()) == 0.0
+    # (b) causality
+    cut = min(1000, L // 2)
+    u2 = t["u"].clone()
+    u2[:, :, cut:] = u2[:, :, cut:] * -0.5 + 1.0
+    out2 = ss.fwd(u2, t["delta"], t["A"], t["B"], t["C"], t["D"], t["z"], t["delta_bias"], True)[0]
+    assert torch.equal(out2[:, :, :cut], out[:, :, :cut])
+    # (c) linearity in u without gating (fp32 I/O only: rounding breaks exact additivity in 16 bit)
+    if dtype == torch.float32:
+        f = lambda uu: ss.fwd(uu, t["delta"], t["A"], t["B"], t["C"], t["D"], None, t["delta_bias"], True)[0]
+        assert rel_err(f(t["u"] + u2), f(t["u"]) + f(u2)) < 1e-5
+
+
+@pytest.mark.parametrize("cfg,batch,dim,L,dtype", [("cfg2_stage0", 3, 128, 20480, torch.bfloat16),
+                                                   ("cfg3_stage0", 8, 128, 81920, torch.float32)])
+def test_conv_full_size_properties(cfg, batch, dim, L, dtype, cuda, ops):
+    """Full-size conv: oracle on a channel slice; shift equivariance (delaying x by s tokens delays out
+    by s tokens for a bias-free linear conv); dx is the adjoint: <conv(x), g> == <x, conv_bwd(g)>."""
+    _, cc = ops
+    gen = torch.Generator().manual_seed(8)
+    x = torch.randn(dim * 2, batch, L, generator=gen).to(dtype).to(cuda).transpose(0, 1)[:, :dim]
+    w, b = torch.randn(dim, 4, generator=gen).to(cuda), torch.randn(dim, generator=gen).to(cuda)
+    out = cc.causal_conv1d_fwd(x, w, b, True)
+    sel = torch.tensor([0, 7, dim - 1], device=cuda)
+    ref = cpu_oracle.causal_conv1d_fwd(x[:1].index_select(1, sel), w[sel], b[sel], True)
+    assert rel_err(out[:1].index_select(1, sel).float(), _round(ref, dtype)) < _tol(dtype)
+    lin = cc.causal_conv1d_fwd(x, w, None, False)
+    s = 5
+    xs = torch.zeros_like(x)
+    xs[:, :, s:] = x[:, :, :-s]
+    lin_s = cc.causal_conv1d_fwd(xs, w, None, False)
+    assert torch.equal(lin_s[:, :, s:], lin[:, :, :-s])
+    if dtype == torch.float32:
+        g = torch.randn(batch, dim, L, generator=gen).to(cuda)
+        dx, _, _ = cc.causal_conv1d_bwd(x, w, None, g, None, False)
+        lhs = (lin.double() * g.double()).sum()
+        rhs = (x.double() * dx.double()).sum()
+        assert abs(float(lhs - rhs)) / abs(float(lhs)) < 1e-5

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmark: times the four hot-path kernels (through the C ABI) on the stage shapes of a
+BASELINE.json config and prints achieved algorithmic GB/s (SURVEY.md section 8d formulas).
+Usage: python tools/kbench.py [--config 2|3|5] [--iters 20] [--stages 0,1,2,3] [--kernels sf,sb,cf,cb]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import causal_conv1d_cuda as cc  # noqa: E402
+import selective_scan_cuda as ss  # noqa: E402
+
+CONFIGS = {  # batch, nf, image, N, expand, dtype
+    2: (3, 5, 256, 16, 2, torch.bfloat16),
+    3: (8, 5, 512, 16, 2, torch.float32),
+    5: (1, 8, 256, 64, 4, torch.bfloat16),
+}
+DIMS, STRIDES = [64, 128, 320, 512], [4, 8, 16, 32]
+
+
+def alg_bytes(kind, B, D, L, N, s, G=1, W=4):
+    if kind == "sf":
+        return 5 * B * D * L * s + 2 * B * G * N * L * s + 4 * (D * N + 2 * D)
+    if kind == "sb":   # out_z not requested: 8 activation streams
+        return 8 * B * D * L * s + 2 * B * G * N * L * s + 2 * B * G * N * L * 4 + 4 * (2 * D * N + 4 * D)
+    if kind == "cf":
+        return 2 * B * D * L * s + 4 * D * (W + 1)
+    return 3 * B * D * L * s + 8 * D * (W + 1)
+
+
+def timeit(fn, iters, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, default=2)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--stages", default="0,1,2,3")
+    ap.add_argument("--kernels", default="sf,sb,cf,cb")
+    a = ap.parse_args()
+    B, nf, img, N, expand, dt = CONFIGS[a.config]
+    s = torch.finfo(dt).bits // 8
+    dev = torch.device("cuda:0")
+    print(f"config {a.config}: B={B} nf={nf} img={img} N={N} expand={expand} dtype={dt}")
+    for st in map(int, a.stages.split(",")):
+        D = DIMS[st] * expand
+        L = nf * (img // STRIDES[st]) ** 2
+        mk = lambda *sh: torch.randn(*sh, device=dev).to(dt)
+        strided = lambda: mk(D, B, L).transpose(0, 1)
+        u, delta, z, dout = strided(), (0.2 * torch.randn(D, B, L, device=dev)).to(dt).transpose(0, 1), strided(), strided()
+        A = -torch.arange(1, N + 1, device=dev, dtype=torch.float32).repeat(D, 1)
+        Bm, Cm = mk(B, 1, N, L), mk(B, 1, N, L)
+        Dv, bias = torch.ones(D, device=dev), torch.full((D,), -4.0, device=dev)
+        w, cb = torch.randn(D, 4, device=dev), torch.randn(D, device=dev)
+        out, x, out_z = ss.fwd(u, delta, A, Bm, Cm, Dv, z, bias, True)
+        dz = torch.empty_like(z)
+        runs = {
+            "sf": lambda: ss.fwd(u, delta, A, Bm, Cm, Dv, z, bias, True),
+            "sb": lambda: ss.bwd(u, delta, A, Bm, Cm, Dv, z, bias, dout, x, out, dz, True, False),
+            "cf": lambda: cc.causal_conv1d_fwd(u, w, cb, True),
+            "cb": lambda: cc.causal_conv1d_bwd(u, w, cb, dout, None, True),
+        }
+        for k in a.kernels.split(","):
+            t = timeit(runs[k], a.iters)
+            nb = alg_bytes(k, B, D, L, N, s)
+            print(f"  stage {st} D={D:5d} L={L:6d} {k}: {t * 1e6:9.1f} us  {nb / 1e6:8.1f} MB  {nb / t / 1e9:8.1f} GB/s "
+                  f"({nb / t / 8e12 * 100:5.1f}% of 8 TB/s)", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,95 @@
+"""Drop-in for the reference's `causal_conv1d_cuda` extension module (pybind surface at
+causal-conv1d/csrc/causal_conv1d.cpp:329-333): `causal_conv1d_fwd` / `causal_conv1d_bwd` with the same
+positional signatures, checks and returns, on the gfx950 kernels behind include/vivim_hip.h.
+`causal_conv1d_update` (single-token decode, unused by Vivim) is not built and says so.
+"""
+import torch
+
+from . import _lib
+
+_DT = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}
+
+
+def _check(cond, msg):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _checks(x, weight, bias_):
+    """causal_conv1d.cpp:135-163."""
+    _check(x.dtype in _DT, "causal_conv1d not implemented for input type '%s'" % x.dtype)
+    _check(weight.dtype in _DT, "causal_conv1d not implemented for weight type '%s'" % weight.dtype)
+    _check(x.is_cuda and weight.is_cuda, "x and weight must be CUDA/HIP tensors")
+    _check(x.dim() == 3 and weight.dim() == 2, "x must be (batch, dim, seqlen) and weight (dim, width)")
+    batch, dim, seqlen = x.shape
+    width = weight.shape[-1]
+    _check(tuple(weight.shape) == (dim, width), "weight must have shape (dim, width)")
+    _check(x.stride(2) == 1 or x.stride(1) == 1, "x must have unit stride along seqlen or along channels")
+    if x.stride(1) == 1 and x.stride(2) > 1:
+        raise RuntimeError("causal_conv1d: channel-last layout is not built in this MI355X port "
+                           "(Vivim's x always has unit seqlen stride); pass x.contiguous()")
+    _check(2 <= width <= 4, "causal_conv1d only supports width between 2 and 4")
+    if bias_ is not None:
+        _check(bias_.dtype == weight.dtype and bias_.is_cuda and bias_.stride(-1) == 1
+               and tuple(bias_.shape) == (dim,), "bias must be a contiguous (dim,) tensor of weight's dtype")
+    return batch, dim, seqlen, width
+
+
+def _fill(P, x, weight, bias_, silu_activation, dims):
+    P.batch, P.dim, P.seqlen, P.width = dims
+    P.itype, P.wtype = _DT[x.dtype], _DT[weight.dtype]
+    P.silu_activation = int(bool(silu_activation))
+    P.x_batch_stride, P.x_c_stride, P.x_l_stride = x.stride()
+    P.weight_c_stride, P.weight_width_stride = weight.stride()
+    P.x, P.weight = x.data_ptr(), weight.data_ptr()
+    P.bias = None if bias_ is None else bias_.data_ptr()
+
+
+def causal_conv1d_fwd(x, weight, bias_, silu_activation):
+    """-> out (empty_like(x)); causal_conv1d.cpp:130-189."""
+    dims = _checks(x, weight, bias_)
+    out = torch.empty_like(x)
+    if out.stride(2) != 1:       # empty_like of an exotic view may not keep unit seqlen stride
+        out = torch.empty(x.shape, device=x.device, dtype=x.dtype)
+    P = _lib.ConvFwdParams()
+    _fill(P, x, weight, bias_, silu_activation, dims)
+    P.out = out.data_ptr()
+    P.out_batch_stride, P.out_c_stride, P.out_l_stride = out.stride()
+    with torch.cuda.device(x.device):
+        _lib.call("vivim_causal_conv1d_fwd", P, torch.cuda.current_stream().cuda_stream)
+    return out
+
+
+def causal_conv1d_bwd(x, weight, bias_, dout, dx_, silu_activation):
+    """-> [dx, dweight, dbias]; causal_conv1d.cpp:191-268."""
+    dims = _checks(x, weight, bias_)
+    batch, dim, seqlen, width = dims
+    _check(dout.is_cuda and dout.dtype == x.dtype and tuple(dout.shape) == (batch, dim, seqlen),
+           "dout must match x")
+    if dout.stride(2) != 1:
+        dout = dout.contiguous()                      # causal_conv1d.cpp:220
+    if dx_ is not None:
+        _check(dx_.dtype == x.dtype and dx_.is_cuda and tuple(dx_.shape) == (batch, dim, seqlen)
+               and dx_.stride(2) == 1, "dx must match x and have stride(2) == 1")
+        dx = dx_
+    else:
+        dx = torch.empty_like(x)
+        if dx.stride(2) != 1:
+            dx = torch.empty(x.shape, device=x.device, dtype=x.dtype)
+    dweight = torch.zeros(weight.shape, device=x.device, dtype=torch.float32)
+    dbias = torch.zeros(dim, device=x.device, dtype=torch.float32) if bias_ is not None else None
+    P = _lib.ConvBwdParams()
+    _fill(P.f, x, weight, bias_, silu_activation, dims)
+    P.dout, P.dx, P.dweight = dout.data_ptr(), dx.data_ptr(), dweight.data_ptr()
+    P.dbias = None if dbias is None else dbias.data_ptr()
+    P.dout_batch_stride, P.dout_c_stride, P.dout_l_stride = dout.stride()
+    P.dx_batch_stride, P.dx_c_stride, P.dx_l_stride = dx.stride()
+    P.dweight_c_stride, P.dweight_width_stride = dweight.stride()
+    with torch.cuda.device(x.device):
+        _lib.call("vivim_causal_conv1d_bwd", P, torch.cuda.current_stream().cuda_stream)
+    return [dx, dweight.to(weight.dtype), dbias.to(bias_.dtype) if bias_ is not None else None]
+
+
+def causal_conv1d_update(x, conv_state, weight, bias_, silu_activation):
+    raise NotImplementedError("causal_conv1d_update (autoregressive decode, causal_conv1d_update.cu:26-86) "
+                              "is outside Vivim's path and is not built yet")

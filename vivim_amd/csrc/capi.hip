@@ -1,0 +1,129 @@
+// capi.hip -- the extern "C" boundary of libvivim_hip.so (see include/vivim_hip.h).
+// Host-side checks mirror the TORCH_CHECKs of the reference bindings that still make sense below the
+// tensor layer (selective_scan.cpp:233-304, 352-438; causal_conv1d.cpp:135-163, 198-238).
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include "../../include/vivim_hip.h"
+
+namespace vivim {
+bool conv_fwd_dispatch(const vivim_conv_fwd_params&, hipStream_t);
+bool conv_bwd_dispatch(const vivim_conv_bwd_params&, hipStream_t);
+bool ssm_fwd_dispatch(const vivim_ssm_fwd_params&, hipStream_t);
+bool ssm_bwd_dispatch(const vivim_ssm_bwd_params&, hipStream_t);
+int scan_chunk_len(int itype);
+}  // namespace vivim
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define VCHECK(cond)                                                                   \
+    do {                                                                               \
+        if (!(cond)) return fail(VIVIM_ERR_INVALID, "%s: check failed: %s", __func__, #cond); \
+    } while (0)
+
+static int after_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(VIVIM_ERR_LAUNCH, "%s: launch failed: %s", what, hipGetErrorString(e));
+    return VIVIM_OK;
+}
+
+static bool dtype_ok(int t) { return t == VIVIM_F32 || t == VIVIM_F16 || t == VIVIM_BF16; }
+
+static int check_ssm_fwd(const vivim_ssm_fwd_params* p, bool is_bwd) {
+    VCHECK(p != nullptr);
+    VCHECK(dtype_ok(p->itype));
+    VCHECK(p->batch > 0 && p->dim > 0 && p->seqlen > 0 && p->dstate > 0 && p->n_groups > 0);
+    VCHECK(p->dstate <= 256);                       // selective_scan.cpp:262
+    VCHECK(p->dim % p->n_groups == 0);
+    VCHECK(p->u && p->delta && p->A && p->B && p->C);
+    VCHECK(p->x != nullptr || (is_bwd && p->seqlen <= vivim::scan_chunk_len(p->itype)));
+    if (!is_bwd) VCHECK(p->out != nullptr);
+    if (p->z) {
+        if (!is_bwd) VCHECK(p->out_z != nullptr);
+        else VCHECK(p->out != nullptr);             // selective_scan.cpp:423 (saved out needed for dz)
+    }
+    if (p->is_variable_B != p->is_variable_C)
+        return fail(VIVIM_ERR_UNSUPPORTED,
+                    "selective_scan: mixed constant/variable B and C is not built (Vivim uses variable B and C)");
+    if (!p->is_variable_B) VCHECK(p->n_groups == 1);
+    return VIVIM_OK;
+}
+
+extern "C" {
+
+int vivim_abi_version(void) { return VIVIM_ABI_VERSION; }
+const char* vivim_last_error(void) { return g_err; }
+int vivim_scan_chunk_len(int itype) { return vivim::scan_chunk_len(itype); }
+size_t vivim_sizeof(int which) {
+    switch (which) {
+        case 0: return sizeof(vivim_ssm_fwd_params);
+        case 1: return sizeof(vivim_ssm_bwd_params);
+        case 2: return sizeof(vivim_conv_fwd_params);
+        case 3: return sizeof(vivim_conv_bwd_params);
+    }
+    return 0;
+}
+
+int vivim_selective_scan_fwd(const vivim_ssm_fwd_params* p, void* stream) {
+    if (int rc = check_ssm_fwd(p, false)) return rc;
+    if (!vivim::ssm_fwd_dispatch(*p, static_cast<hipStream_t>(stream)))
+        return fail(VIVIM_ERR_UNSUPPORTED, "selective_scan_fwd not implemented for input type %d", p->itype);
+    return after_launch("selective_scan_fwd");
+}
+
+int vivim_selective_scan_bwd(const vivim_ssm_bwd_params* p, void* stream) {
+    VCHECK(p != nullptr);
+    if (int rc = check_ssm_fwd(&p->f, true)) return rc;
+    VCHECK(p->dout && p->du && p->ddelta && p->dA && p->dB && p->dC);
+    VCHECK((p->f.D == nullptr) == (p->dD == nullptr));
+    VCHECK((p->f.delta_bias == nullptr) == (p->ddelta_bias == nullptr));
+    VCHECK((p->f.z == nullptr) == (p->dz == nullptr));
+    if (!vivim::ssm_bwd_dispatch(*p, static_cast<hipStream_t>(stream)))
+        return fail(VIVIM_ERR_UNSUPPORTED, "selective_scan_bwd not implemented for input type %d", p->f.itype);
+    return after_launch("selective_scan_bwd");
+}
+
+static int check_conv(const vivim_conv_fwd_params* p) {
+    VCHECK(p != nullptr);
+    VCHECK(dtype_ok(p->itype) && dtype_ok(p->wtype));
+    VCHECK(p->batch > 0 && p->dim > 0 && p->seqlen > 0);
+    VCHECK(p->batch <= 65535 && p->dim <= 65535);
+    if (!(p->width >= 2 && p->width <= 4))          // causal_conv1d.cpp:157
+        return fail(VIVIM_ERR_INVALID, "causal_conv1d only supports width between 2 and 4");
+    VCHECK(p->x && p->weight);
+    if (p->x_l_stride != 1)
+        return fail(VIVIM_ERR_UNSUPPORTED,
+                    "causal_conv1d: channel-last layout is not built (Vivim's x has unit seqlen stride)");
+    return VIVIM_OK;
+}
+
+int vivim_causal_conv1d_fwd(const vivim_conv_fwd_params* p, void* stream) {
+    if (int rc = check_conv(p)) return rc;
+    VCHECK(p->out != nullptr && p->out_l_stride == 1);
+    if (!vivim::conv_fwd_dispatch(*p, static_cast<hipStream_t>(stream)))
+        return fail(VIVIM_ERR_UNSUPPORTED, "causal_conv1d_fwd not implemented for input type %d / weight type %d",
+                    p->itype, p->wtype);
+    return after_launch("causal_conv1d_fwd");
+}
+
+int vivim_causal_conv1d_bwd(const vivim_conv_bwd_params* p, void* stream) {
+    VCHECK(p != nullptr);
+    if (int rc = check_conv(&p->f)) return rc;
+    VCHECK(p->dout && p->dx && p->dweight);
+    VCHECK(p->dout_l_stride == 1 && p->dx_l_stride == 1);   // causal_conv1d.cpp:220, 236
+    VCHECK((p->f.bias == nullptr) == (p->dbias == nullptr));
+    if (!vivim::conv_bwd_dispatch(*p, static_cast<hipStream_t>(stream)))
+        return fail(VIVIM_ERR_UNSUPPORTED, "causal_conv1d_bwd not implemented for input type %d / weight type %d",
+                    p->f.itype, p->f.wtype);
+    return after_launch("causal_conv1d_bwd");
+}
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+"""`Mamba` module with the reference fork's tri-directional "v3" block
+(mamba/mamba_ssm/modules/mamba_simple.py:34-264): same constructor arguments, parameter names
+(so reference checkpoints load: in_proj, conv1d{,_b,_s}, x_proj{,_b,_s}, dt_proj{,_b,_s},
+A{,_b,_s}_log, D{,_b,_s}, out_proj) and forward semantics.
+
+Deliberate differences:
+  * `nframes` is honoured per call: the reference hard-codes 5 (mamba_simple.py:54) and its
+    chunk/stack re-ordering raises for clips whose token count is not 5 equal chunks; here the
+    frame-major -> pixel-major permutation is an exact reshape for any nframes dividing seqlen.
+  * decode-time `step` / inference cache (mamba_simple.py:356-443) is outside Vivim's path: not built.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .selective_scan_interface import mamba_inner_fn_no_out_proj
+
+_DIRECTIONS = ("", "_b", "_s")     # forward in time, backward in time, spatial (pixel-major) order
+
+
+class Mamba(nn.Module):
+    def __init__(self, d_model, d_state=16, d_conv=4, expand=2, dt_rank="auto", dt_min=0.001, dt_max=0.1,
+                 dt_init="random", dt_scale=1.0, dt_init_floor=1e-4, conv_bias=True, bias=False,
+                 use_fast_path=True, layer_idx=None, device=None, dtype=None, bimamba_type="none",
+                 nframes=5):
+        kw = {"device": device, "dtype": dtype}
+        super().__init__()
+        assert bimamba_type == "v3", "this fork only builds the tri-directional v3 block (mamba_simple.py:125)"
+        self.d_model, self.d_state, self.d_conv, self.expand = d_model, d_state, d_conv, expand
+        self.d_inner = int(expand * d_model)
+        self.dt_rank = math.ceil(d_model / 16) if dt_rank == "auto" else dt_rank
+        self.use_fast_path = use_fast_path
+        self.layer_idx = layer_idx
+        self.bimamba_type = bimamba_type
+        self.nframes = nframes
+        self.activation = "silu"
+
+        self.in_proj = nn.Linear(d_model, 2 * self.d_inner, bias=bias, **kw)
+        for sfx in _DIRECTIONS:
+            self.add_module("conv1d" + sfx, nn.Conv1d(self.d_inner, self.d_inner, kernel_size=d_conv,
+                                                      groups=self.d_inner, padding=d_conv - 1,
+                                                      bias=conv_bias, **kw))
+            self.add_module("x_proj" + sfx, nn.Linear(self.d_inner, self.dt_rank + 2 * d_state, bias=False, **kw))
+            dt_proj = nn.Linear(self.dt_rank, self.d_inner, bias=True, **kw)
+            self.add_module("dt_proj" + sfx, dt_proj)
+            if sfx == "":
+                # variance-preserving dt weights and softplus^-1(U_log[dt_min, dt_max]) bias are applied to
+                # the forward direction only in the reference (mamba_simple.py:89-108)
+                std = self.dt_rank ** -0.5 * dt_scale
+                if dt_init == "constant":
+                    nn.init.constant_(dt_proj.weight, std)
+                elif dt_init == "random":
+                    nn.init.uniform_(dt_proj.weight, -std, std)
+                else:
+                    raise NotImplementedError
+                dt = torch.exp(torch.rand(self.d_inner, **kw) * (math.log(dt_max) - math.log(dt_min))
+                               + math.log(dt_min)).clamp(min=dt_init_floor)
+                with torch.no_grad():
+                    dt_proj.bias.copy_(dt + torch.log(-torch.expm1(-dt)))
+                dt_proj.bias._no_reinit = True
+            # S4D-real A = -(1..N), kept as fp32 log; D = 1 (mamba_simple.py:110-123)
+            A_log = torch.log(torch.arange(1, d_state + 1, dtype=torch.float32, device=device)
+                              ).repeat(self.d_inner, 1).contiguous()
+            a_name = f"A{sfx}_log"
+            self.register_parameter(a_name, nn.Parameter(A_log))
+            getattr(self, a_name)._no_weight_decay = True
+            d_name = "D" + sfx
+            self.register_parameter(d_name, nn.Parameter(torch.ones(self.d_inner, device=device)))
+            getattr(self, d_name)._no_weight_decay = True
+        self.out_proj = nn.Linear(self.d_inner, d_model, bias=bias, **kw)
+
+    def _inner(self, xz, sfx):
+        conv, x_proj, dt_proj = (getattr(self, n + sfx) for n in ("conv1d", "x_proj", "dt_proj"))
+        A = -torch.exp(getattr(self, f"A{sfx}_log").float())
+        return mamba_inner_fn_no_out_proj(
+            xz, conv.weight, conv.bias, x_proj.weight, dt_proj.weight, A, None, None,
+            getattr(self, "D" + sfx).float(), delta_bias=dt_proj.bias.float(), delta_softplus=True)
+
+    def forward(self, hidden_states, inference_params=None, nframes=None):
+        """hidden_states: (B, L, d_model) with L = nframes * H * W in frame-major order -> same shape."""
+        if inference_params is not None:
+            raise NotImplementedError("decode-time inference cache is outside Vivim's path")
+        batch, seqlen, _ = hidden_states.shape
+        nf = self.nframes if nframes is None else nframes
+        if seqlen % nf != 0:
+            raise ValueError(f"seqlen {seqlen} is not a multiple of nframes {nf}")
+        # in_proj and the BLD -> (B, 2*d_inner, L) transpose in one matmul; xz strides are (L, B*L, 1)
+        xz = (self.in_proj.weight @ hidden_states.reshape(batch * seqlen, -1).t()
+              ).view(2 * self.d_inner, batch, seqlen).transpose(0, 1)
+        if self.in_proj.bias is not None:
+            xz = xz + self.in_proj.bias.to(xz.dtype)[:, None]
+        out = self._inner(xz, "")
+        out_b = self._inner(xz.flip([-1]), "_b").flip([-1])
+        hw = seqlen // nf
+        # token t*hw + p  ->  p*nf + t  (what chunk(nf) + stack(-1) + flatten does, mamba_simple.py:245-247)
+        xz_s = xz.reshape(batch, 2 * self.d_inner, nf, hw).transpose(2, 3).reshape(batch, 2 * self.d_inner, seqlen)
+        out_s = self._inner(xz_s, "_s")
+        out_s = out_s.reshape(batch, self.d_inner, hw, nf).transpose(2, 3).reshape(batch, self.d_inner, seqlen)
+        y = (out + out_b + out_s).transpose(1, 2) / 3
+        return F.linear(y, self.out_proj.weight, self.out_proj.bias)

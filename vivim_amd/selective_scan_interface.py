@@ -1,0 +1,194 @@
+"""Autograd surface of the selective scan and of the fused Mamba inner op.
+
+Same names, argument order, saved-tensor policy and return tuples as the reference's
+mamba/mamba_ssm/ops/selective_scan_interface.py:
+  SelectiveScanFn / selective_scan_fn                       :14-83
+  MambaInnerFnNoOutProj / mamba_inner_fn_no_out_proj        :155-289, :627-633   (what Vivim calls)
+  mamba_inner_fn                                            :606-615  (composition with out_proj)
+The CUDA extension calls are replaced by vivim_amd.selective_scan_cuda / causal_conv1d_cuda (gfx950
+kernels behind the C ABI); the GEMMs inside the fused op stay on PyTorch-ROCm (hipBLASLt), as in the
+reference where they are plain torch matmuls (:181-182, :272-277).
+"""
+import torch
+import torch.nn.functional as F
+from torch.amp import custom_bwd, custom_fwd
+
+from . import causal_conv1d_cuda, selective_scan_cuda
+
+
+def _unit_l(t):
+    return t if t is None or t.stride(-1) == 1 else t.contiguous()
+
+
+class SelectiveScanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
+                return_last_state=False):
+        u, delta, B, C, z = (_unit_l(t) for t in (u, delta, B, C, z))
+        if D is not None:
+            D = D.contiguous()
+        ctx.squeeze_B = B.dim() == 3
+        ctx.squeeze_C = C.dim() == 3
+        if ctx.squeeze_B:
+            B = B.unsqueeze(1)
+        if ctx.squeeze_C:
+            C = C.unsqueeze(1)
+        out, x, *rest = selective_scan_cuda.fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus)
+        ctx.delta_softplus = delta_softplus
+        ctx.has_z = z is not None
+        last_state = x[:, :, -1, :]                       # (batch, dim, dstate); reference: x[:, :, -1, 1::2]
+        if ctx.has_z:
+            ctx.save_for_backward(u, delta, A, B, C, D, z, delta_bias, x, out)
+            result = rest[0]
+        else:
+            ctx.save_for_backward(u, delta, A, B, C, D, delta_bias, x)
+            result = out
+        return (result, last_state) if return_last_state else result
+
+    @staticmethod
+    def backward(ctx, dout, *ignored):
+        if ctx.has_z:
+            u, delta, A, B, C, D, z, delta_bias, x, out = ctx.saved_tensors
+        else:
+            u, delta, A, B, C, D, delta_bias, x = ctx.saved_tensors
+            z = out = None
+        dout = _unit_l(dout)
+        du, ddelta, dA, dB, dC, dD, ddelta_bias, *rest = selective_scan_cuda.bwd(
+            u, delta, A, B, C, D, z, delta_bias, dout, x, out, None, ctx.delta_softplus, False)
+        dz = rest[0] if ctx.has_z else None
+        if ctx.squeeze_B:
+            dB = dB.squeeze(1)
+        if ctx.squeeze_C:
+            dC = dC.squeeze(1)
+        return (du, ddelta, dA, dB, dC, dD if D is not None else None, dz,
+                ddelta_bias if delta_bias is not None else None, None, None)
+
+
+def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
+                      return_last_state=False):
+    """If return_last_state, returns (out, last_state) with last_state (batch, dim, dstate); the gradient
+    of last_state is not propagated (as in the reference, :79-82)."""
+    return SelectiveScanFn.apply(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state)
+
+
+class MambaInnerFnNoOutProj(torch.autograd.Function):
+    """conv1d+SiLU -> x_proj -> dt_proj -> selective scan (+D, gated by silu(z)) as ONE autograd node with
+    activation recompute: conv1d_out and delta are dropped after the forward and rebuilt in the backward
+    (checkpoint_lvl=1, reference :218-219, :238-241)."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda")
+    def forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
+                A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None,
+                delta_softplus=True, checkpoint_lvl=1):
+        assert checkpoint_lvl in (0, 1)
+        if A.is_complex():
+            raise NotImplementedError("complex A is outside Vivim's path (A is real fp32, mamba_simple.py:212)")
+        batch, _, L = xz.shape
+        R = delta_proj_weight.shape[1]
+        N = A.shape[-1]
+        if torch.is_autocast_enabled("cuda"):
+            amp_dtype = torch.get_autocast_dtype("cuda")
+            x_proj_weight = x_proj_weight.to(amp_dtype)
+            delta_proj_weight = delta_proj_weight.to(amp_dtype)
+        xz = _unit_l(xz)
+        conv1d_weight = conv1d_weight.squeeze(1)                       # (d, 1, w) -> (d, w)
+        x, z = xz.chunk(2, dim=1)
+        conv1d_bias = conv1d_bias.contiguous() if conv1d_bias is not None else None
+        conv1d_out = causal_conv1d_cuda.causal_conv1d_fwd(x, conv1d_weight, conv1d_bias, True)
+        d_inner = conv1d_out.shape[1]
+        # (b d l) -> ((b l) d) @ W_x^T : (b l, R + 2N); delta keeps d slowest / l fastest for the scan
+        x_dbl = F.linear(conv1d_out.transpose(1, 2).reshape(batch * L, d_inner), x_proj_weight)
+        delta = (delta_proj_weight @ x_dbl[:, :R].t()).view(d_inner, batch, L).transpose(0, 1)
+        ctx.is_variable_B = B is None
+        ctx.is_variable_C = C is None
+        ctx.B_proj_bias_is_None = B_proj_bias is None
+        ctx.C_proj_bias_is_None = C_proj_bias is None
+        if B is None:
+            B = x_dbl[:, R:R + N]
+            if B_proj_bias is not None:
+                B = B + B_proj_bias.to(B.dtype)
+            B = B.view(batch, L, N).transpose(1, 2).unsqueeze(1).contiguous()   # (b, 1, N, l)
+        else:
+            B = _unit_l(B)
+        if C is None:
+            C = x_dbl[:, -N:]
+            if C_proj_bias is not None:
+                C = C + C_proj_bias.to(C.dtype)
+            C = C.view(batch, L, N).transpose(1, 2).unsqueeze(1).contiguous()
+        else:
+            C = _unit_l(C)
+        if D is not None:
+            D = D.contiguous()
+        out, scan_intermediates, out_z = selective_scan_cuda.fwd(
+            conv1d_out, delta, A, B, C, D, z, delta_bias, delta_softplus)
+        ctx.delta_softplus = delta_softplus
+        ctx.checkpoint_lvl = checkpoint_lvl
+        if checkpoint_lvl >= 1:
+            conv1d_out = delta = None
+        ctx.save_for_backward(xz, conv1d_weight, conv1d_bias, x_dbl, x_proj_weight, delta_proj_weight,
+                              conv1d_out, delta, A, B, C, D, delta_bias, scan_intermediates, out)
+        return out_z
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, dout):
+        (xz, conv1d_weight, conv1d_bias, x_dbl, x_proj_weight, delta_proj_weight, conv1d_out, delta,
+         A, B, C, D, delta_bias, scan_intermediates, out) = ctx.saved_tensors
+        batch, _, L = xz.shape
+        R = delta_proj_weight.shape[1]
+        N = A.shape[-1]
+        x, z = xz.chunk(2, dim=1)
+        d_inner = x.shape[1]
+        dout = _unit_l(dout)
+        if ctx.checkpoint_lvl == 1:
+            conv1d_out = causal_conv1d_cuda.causal_conv1d_fwd(x, conv1d_weight, conv1d_bias, True)
+            delta = (delta_proj_weight @ x_dbl[:, :R].t()).view(d_inner, batch, L).transpose(0, 1)
+        # dx and dz are written straight into the two halves of dxz (no torch.cat), reference :244-251
+        dxz = torch.empty_like(xz)
+        dx, dz = dxz.chunk(2, dim=1)
+        # The reference asks the kernel to recompute out_z here and drops it (:247-251); we do not ask.
+        dconv1d_out, ddelta, dA, dB, dC, dD, ddelta_bias, dz = selective_scan_cuda.bwd(
+            conv1d_out, delta, A, B, C, D, z, delta_bias, dout, scan_intermediates, out, dz,
+            ctx.delta_softplus, False)
+        dx_dbl = torch.empty_like(x_dbl)
+        dB_proj_bias = dC_proj_bias = None
+        if ctx.is_variable_B:
+            dB = dB.squeeze(1).transpose(1, 2).reshape(batch * L, N)       # (b 1 N l) -> ((b l) N)
+            dB_proj_bias = dB.sum(0) if not ctx.B_proj_bias_is_None else None
+            dx_dbl[:, R:R + N] = dB
+            dB = None
+        if ctx.is_variable_C:
+            dC = dC.squeeze(1).transpose(1, 2).reshape(batch * L, N)
+            dC_proj_bias = dC.sum(0) if not ctx.C_proj_bias_is_None else None
+            dx_dbl[:, -N:] = dC
+            dC = None
+        ddelta = ddelta.transpose(0, 1).reshape(d_inner, batch * L)        # (b d l) -> (d (b l))
+        ddelta_proj_weight = ddelta @ x_dbl[:, :R]
+        dx_dbl[:, :R] = ddelta.t() @ delta_proj_weight
+        dconv1d_out = dconv1d_out.transpose(0, 1).reshape(d_inner, batch * L)
+        dx_proj_weight = dx_dbl.t() @ conv1d_out.transpose(1, 2).reshape(batch * L, d_inner)
+        dconv1d_out = torch.addmm(dconv1d_out, x_proj_weight.t(), dx_dbl.t())
+        dconv1d_out = dconv1d_out.view(d_inner, batch, L).transpose(0, 1)  # -> (b d l), unit l stride
+        dx, dconv1d_weight, dconv1d_bias = causal_conv1d_cuda.causal_conv1d_bwd(
+            x, conv1d_weight, conv1d_bias, dconv1d_out, dx, True)
+        return (dxz, dconv1d_weight.unsqueeze(1), dconv1d_bias if conv1d_bias is not None else None,
+                dx_proj_weight, ddelta_proj_weight, dA, dB, dC, dD if D is not None else None,
+                ddelta_bias if delta_bias is not None else None, dB_proj_bias, dC_proj_bias, None, None)
+
+
+def mamba_inner_fn_no_out_proj(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
+                               A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None,
+                               C_proj_bias=None, delta_softplus=True):
+    """xz: (batch, 2*d_inner, seqlen) -> (batch, d_inner, seqlen)."""
+    return MambaInnerFnNoOutProj.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
+                                       A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus)
+
+
+def mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
+                   out_proj_weight, out_proj_bias, A, B=None, C=None, D=None, delta_bias=None,
+                   B_proj_bias=None, C_proj_bias=None, delta_softplus=True):
+    """Same math as the reference's MambaInnerFn (:292-434): the fused inner op followed by out_proj."""
+    y = mamba_inner_fn_no_out_proj(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
+                                   A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus)
+    return F.linear(y.transpose(1, 2), out_proj_weight, out_proj_bias)
