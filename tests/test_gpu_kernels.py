@@ -213,7 +213,12 @@ def test_scan_golden(name, cuda, ops):
     has_z = "z" in g
     exp_f = (None if has_z else g["out"], g["out"] if has_z else None, g["last_state"])
     exp_b = {k: g.get(k) for k in ("du", "ddelta", "dA", "dB", "dC", "dD", "dz", "ddelta_bias")}
-    _check_scan(t, ss, exp_f, exp_b, tol=_tol(t["dtype"]) if t["dtype"] == torch.float32 else 2e-3)
+    # 16-bit fixtures: the reference's selective_scan_ref evaluates silu(z) in the 16-bit dtype
+    # (selective_scan_interface.py:149-150: z is never up-cast) while its CUDA kernel -- and ours, and the C
+    # oracle -- use fp32 (fwd_kernel.cuh:288-291), so ref-vs-kernel differs by ~1 ulp of the I/O dtype; the
+    # reference's own test tolerance for that is rtol/atol 3e-2/5e-2 (bf16).  The 1e-3 bound is enforced
+    # against the oracle (kernel semantics) in the tests below.
+    _check_scan(t, ss, exp_f, exp_b, tol=_tol(t["dtype"]) if t["dtype"] == torch.float32 else 5e-3)
 
 
 def _rand_scan(gen, batch, dim, N, L, G, dtype, dev, has_z=True, has_D=True, has_bias=True, softplus=True,
