@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: frames/sec of one Vivim train step (fwd + loss + bwd + AdamW) at
+256x256, clip_length 5, 3 classes, per-GPU batch 3, bf16 autocast (BASELINE.json configs[1]); weak scaling
+over N GPUs (one process per GPU, RCCL gradient all-reduce overlapped with the backward by DDP buckets).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      -- the dominant hot-path kernel (largest total time among the four C-ABI kernels), its
+                   algorithmic bytes (vivim_amd/_lib.py:algorithmic_bytes) divided by its
+                   HIP-event time, both summed over every launch inside the timed region;
+  cpu_baseline  -- the pure-PyTorch selective_scan_ref port (oracle/ref_torch.py) timed on this host's cores
+                   on a bounded sample (N = 1 only).
+Synthetic data, random-init weights (SegFormer-b3 architecture from a local config): there is no network.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("-image_size", "--image-size", type=int, default=256)
+    ap.add_argument("-clip_length", "--clip-length", type=int, default=5)
+    ap.add_argument("-train_bs", "--train-bs", type=int, default=3)
+    ap.add_argument("-num_classes", "--num-classes", type=int, default=3)
+    ap.add_argument("-seed", "--seed", type=int, default=42)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--d-state", type=int, default=16)
+    ap.add_argument("--expand", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """Times the pure-PyTorch selective_scan_ref port on the host CPUs: stage-0 scan shape of the benchmarked
+    config at batch 1 (D=128, N=16, L=20480), fp32, forward only -- the reference's CPU-runnable path
+    (BASELINE.json configs[0]).  Reported in algorithmic GB/s like the roofline."""
+    from oracle import ref_torch
+    D, N, L = 128, 16, 20480
+    g = torch.Generator().manual_seed(0)
+    u = torch.randn(1, D, L, generator=g)
+    delta = 0.5 * torch.rand(1, D, L, generator=g)
+    A = -0.5 * torch.rand(D, N, generator=g)
+    Bm, Cm = torch.randn(1, N, L, generator=g), torch.randn(1, N, L, generator=g)
+    Dv, z = torch.randn(D, generator=g), torch.randn(1, D, L, generator=g)
+    bias = 0.5 * torch.rand(D, generator=g)
+    cores = torch.get_num_threads()
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 3 and (time.perf_counter() - t_start) < seconds_budget:
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            ref_torch.selective_scan_ref(u, delta, A, Bm, Cm, Dv, z=z, delta_bias=bias, delta_softplus=True)
+        times.append(time.perf_counter() - t0)
+    best = min(times)
+    nbytes = 5 * D * L * 4 + 2 * N * L * 4 + 4 * (D * N + 2 * D)
+    return {"value": round(nbytes / best / 1e9, 5), "unit": "GB/s", "cores": cores, "kind": "port",
+            "sample": f"selective_scan_ref port fwd, (B,D,N,L)=(1,{D},{N},{L}) fp32, best of {len(times)}; "
+                      f"{best:.2f} s per call = {L / best:.0f} tokens/s on {os.cpu_count()} host cpus"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)        # RCCL over xGMI
+    amp = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[a.dtype]
+
+    from vivim_amd import _lib
+    from vivim_amd.train_step import build_model, make_optimizer, synthetic_batch, train_step
+    _lib.lib()                                                 # fail loudly if the HIP library is missing
+
+    torch.manual_seed(a.seed)                                  # identical replicas
+    model = build_model(a.num_classes, dev, mamba_kwargs={"d_state": a.d_state, "expand": a.expand})
+    step_model = model
+    if world > 1:
+        # bucketed all-reduce (25 MB) in reverse registration order: the stage-3/2 buckets are in flight
+        # while the long stage-0/1 backward scans still run.
+        step_model = torch.nn.parallel.DistributedDataParallel(
+            model, device_ids=[local_rank], bucket_cap_mb=25, gradient_as_bucket_view=True, static_graph=True)
+    opt = make_optimizer(model)
+    clip, onehot = synthetic_batch(a.train_bs, a.clip_length, a.image_size, a.num_classes, dev, a.seed + rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        train_step(step_model, opt, clip, onehot, a.num_classes, amp)
+    barrier()
+    _lib.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = train_step(step_model, opt, clip, onehot, a.num_classes, amp)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    records = _lib.profile_end()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(loss), "non-finite loss"
+
+    if rank == 0:
+        frames = world * a.train_bs * a.clip_length * a.steps
+        per = {}
+        for name, nbytes, sec in records:
+            e = per.setdefault(name, [0, 0.0, 0])
+            e[0] += nbytes
+            e[1] += sec
+            e[2] += 1
+        dom = max(per, key=lambda k: per[k][1])
+        ach = per[dom][0] / per[dom][1] / 1e9
+        kernels = {k.replace("vivim_", ""): {"launches": v[2], "total_ms": round(v[1] * 1e3, 3),
+                                              "avg_us": round(v[1] / v[2] * 1e6, 2),
+                                              "alg_GBps": round(v[0] / v[1] / 1e9, 1)} for k, v in per.items()}
+        out = {
+            "metric": "frames/sec fwd+bwd, 256x256 clip=5 3-class", "value": round(frames / elapsed, 3),
+            "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": "Vivim train step (fwd+loss+bwd+AdamW), BASELINE.json configs[1]",
+                       "image_size": a.image_size, "clip_length": a.clip_length, "num_classes": a.num_classes,
+                       "per_gpu_batch": a.train_bs, "global_batch": a.train_bs * world, "d_state": a.d_state,
+                       "backbone": "SegFormer-b3 architecture, random init", "parallelism": f"dp{world}"},
+            "roofline": {"bound": "hbm", "kernel": dom.replace("vivim_", ""), "achieved": round(ach, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                         "traffic": None, "launches": per[dom][2],
+                         "avg_launch_us": round(per[dom][1] / per[dom][2] * 1e6, 2)},
+            "kernels": kernels,
+            "loss": round(float(loss), 5),
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

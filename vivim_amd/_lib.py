@@ -103,10 +103,65 @@ def lib():
     return _lib
 
 
+_ISIZE = {F32: 4, F16: 2, BF16: 2}
+
+
+def algorithmic_bytes(name, P):
+    """Compulsory HBM traffic of one launch: every tensor of the op read or written once
+    (the checkpoint tensor x is an implementation choice and is excluded)."""
+    if name.startswith("vivim_selective_scan"):
+        f = P.f if name.endswith("bwd") else P
+        s = _ISIZE[f.itype]
+        act = f.batch * f.dim * f.seqlen * s
+        bc = (f.batch * f.n_groups * f.dstate * f.seqlen) if f.is_variable_B else f.dim * f.dstate
+        has_z = bool(f.z)
+        if name.endswith("fwd"):
+            n_act = 3 + (2 if has_z else 0)                       # u, delta, out (+ z, out_z)
+            return n_act * act + 2 * bc * (s if f.is_variable_B else 4) + 4 * (f.dim * f.dstate + 2 * f.dim)
+        n_act = 5 + (3 if has_z else 0) + (1 if (has_z and f.out_z) else 0)   # u, delta, dout, du, ddelta (+ z, out, dz) (+ out_z)
+        return (n_act * act + 2 * bc * (s if f.is_variable_B else 4) + 2 * bc * 4
+                + 4 * (2 * f.dim * f.dstate + 4 * f.dim))
+    f = P.f if name.endswith("bwd") else P
+    s = _ISIZE[f.itype]
+    act = f.batch * f.dim * f.seqlen * s
+    if name.endswith("fwd"):
+        return 2 * act + 4 * f.dim * (f.width + 1)
+    return 3 * act + 8 * f.dim * (f.width + 1)
+
+
+_profile = None
+
+
+def profile_begin():
+    """Start recording one (name, algorithmic bytes, start event, end event) tuple per C-ABI call; the
+    events are recorded on the stream the kernel is launched on (torch's current stream)."""
+    global _profile
+    _profile = []
+
+
+def profile_end():
+    """Stop recording; -> list of (name, bytes, seconds) after synchronising the recorded events."""
+    global _profile
+    rec, _profile = _profile or [], None
+    out = []
+    for name, nbytes, e0, e1 in rec:
+        e1.synchronize()
+        out.append((name, nbytes, e0.elapsed_time(e1) * 1e-3))
+    return out
+
+
 def call(name, params, stream):
     """Enqueue one entry point on `stream` (int hipStream_t); RuntimeError on a nonzero return,
     like the TORCH_CHECKs of the reference bindings."""
     L = lib()
-    rc = getattr(L, name)(ctypes.byref(params), vp(stream))
+    if _profile is not None:
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(L, name)(ctypes.byref(params), vp(stream))
+        e1.record()
+        _profile.append((name, algorithmic_bytes(name, params), e0, e1))
+    else:
+        rc = getattr(L, name)(ctypes.byref(params), vp(stream))
     if rc != 0:
         raise RuntimeError(L.vivim_last_error().decode())

@@ -1,0 +1,76 @@
+"""Plain-PyTorch counterpart of the reference's Lightning train step (multiclass_training_folds.py:543-573,
+configure_optimizers :503-517, Trainer(precision=16, devices=1) :800-811): Vivim forward under autocast,
+recall_focused_loss, backward, AdamW.  Used by bench.py and the tests; the losses are restated from the
+reference source text (it cannot be imported: it needs pytorch_lightning / wandb / medpy and parses argv at
+import time)."""
+import torch
+import torch.nn.functional as F
+
+
+def tversky_loss(probs, onehot, alpha=0.3, beta=0.7, smooth=1e-6):
+    """multiclass_training_folds.py:218-255: per class and per image, then mean over images and classes."""
+    tp = (probs * onehot).sum(dim=(2, 3))
+    fp = (probs * (1 - onehot)).sum(dim=(2, 3))
+    fn = ((1 - probs) * onehot).sum(dim=(2, 3))
+    tv = (tp + smooth) / (tp + alpha * fp + beta * fn + smooth)          # (N, C)
+    return (1 - tv.mean(dim=0)).mean()
+
+
+def class_balanced_focal_loss(probs, onehot, gamma=2.0, alpha=(0.05, 0.475, 0.475)):
+    """multiclass_training_folds.py:363-423 with explicit alpha."""
+    a = torch.tensor(alpha, device=probs.device, dtype=probs.dtype)[None, :, None, None]
+    weight = onehot * (1 - probs) ** gamma + (1 - onehot) * probs ** gamma
+    bce = -onehot * torch.log(probs + 1e-6) - (1 - onehot) * torch.log(1 - probs + 1e-6)
+    return (a * weight * bce).mean(dim=(0, 2, 3)).sum()
+
+
+def recall_focused_loss(logits, targets, num_classes, gamma=2.0):
+    """0.4 * focal + 0.6 * tversky (multiclass_training_folds.py:339-361). logits (N,C,H,W); targets (N,H,W)."""
+    probs = F.softmax(logits.float(), dim=1)
+    onehot = F.one_hot(targets.long(), num_classes).permute(0, 3, 1, 2).float()
+    alpha = (0.05, 0.475, 0.475) if num_classes == 3 else tuple([1.0 / num_classes] * num_classes)
+    return 0.4 * class_balanced_focal_loss(probs, onehot, gamma, alpha) + 0.6 * tversky_loss(probs, onehot)
+
+
+def build_model(num_classes=3, device="cuda", mamba_kwargs=None, drop_path_rate=0.2):
+    """Vivim with a randomly initialised SegFormer-b3 backbone (no hub access on the GPU box).  The two
+    parameter groups that never receive a gradient in Vivim's forward -- the SegFormer 150-class classifier
+    and the per-stage encoder layer norms (vivim.py:211-212, 325) -- are frozen so DDP needs no
+    unused-parameter search."""
+    from .vivim import Vivim, segformer_b3_random
+    model = Vivim(in_chans=3, out_chans=num_classes, backbone=segformer_b3_random(),
+                  drop_path_rate=drop_path_rate, mamba_kwargs=mamba_kwargs)
+    for p in model.decoder.classifier.parameters():
+        p.requires_grad_(False)
+    for p in model.encoder.downsample_layers.layer_norm.parameters():
+        p.requires_grad_(False)
+    return model.to(device)
+
+
+def make_optimizer(model, lr=1e-4, weight_decay=1e-2):
+    return torch.optim.AdamW((p for p in model.parameters() if p.requires_grad), lr=lr, betas=(0.9, 0.999),
+                             weight_decay=weight_decay)
+
+
+def synthetic_batch(batch, clip_length, image_size, num_classes, device, seed):
+    """clip ~ N(0,1) (the reference normalises frames with ImageNet mean/std, Multiclass_Data.py:24-25);
+    one-hot float target (B, nf, C, H, W) as the dataset yields (Multiclass_Data.py:211-215)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    clip = torch.randn(batch, clip_length, 3, image_size, image_size, generator=g)
+    labels = torch.randint(0, num_classes, (batch, clip_length, image_size, image_size), generator=g)
+    onehot = F.one_hot(labels, num_classes).permute(0, 1, 4, 2, 3).float()
+    return clip.to(device), onehot.to(device)
+
+
+def train_step(model, optimizer, clip, onehot, num_classes, amp_dtype=torch.bfloat16):
+    """One fwd + loss + bwd + optimizer step; returns the detached loss."""
+    model.train()
+    with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype != torch.float32):
+        logits = model(clip)                                   # (B*nf, C, H, W)
+    B, T = onehot.shape[:2]
+    target = onehot.argmax(dim=2).view(B * T, *onehot.shape[-2:])
+    loss = recall_focused_loss(logits, target, num_classes)
+    optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    optimizer.step()
+    return loss.detach()
