@@ -7,6 +7,7 @@
 namespace vivim {
 
 constexpr int kWave = 64;
+constexpr int kChunk = 256;   // tokens per row of the checkpoint tensor x (contract between fwd and bwd kernels)
 constexpr float kLog2e = 1.4426950408889634f;
 
 using f16_t = _Float16;
@@ -40,6 +41,7 @@ template <typename T, int BYTES> struct Pack;
 template <typename T> struct Pack<T, 16> { using type = u32x4; };
 template <typename T> struct Pack<T, 8> { using type = u32x2; };
 template <typename T> struct Pack<T, 4> { using type = uint32_t; };
+template <typename T> struct Pack<T, 2> { using type = uint16_t; };
 
 // nv = number of valid elements at p[0..K) (<=0: none). Invalid slots read as 0.
 template <typename T, int K>
@@ -85,6 +87,92 @@ __device__ __forceinline__ void store_k(T* __restrict__ p, int nv, const float (
     }
 }
 
+// Raw (unconverted) K elements kept in registers, so a load can be issued long before its use.
+template <typename T, int K> struct RawK { T e[K]; };
+
+template <typename T, int K>
+__device__ __forceinline__ RawK<T, K> load_raw(const T* __restrict__ p, int nv) {
+    constexpr int BYTES = K * (int)sizeof(T);
+    constexpr int VB = BYTES >= 16 ? 16 : BYTES;
+    constexpr int NV = BYTES / VB;
+    constexpr int EPV = VB / (int)sizeof(T);
+    RawK<T, K> r;
+    if (nv >= K && (reinterpret_cast<uintptr_t>(p) & (VB - 1)) == 0) {
+        using V = typename Pack<T, VB>::type;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            union { V raw; T e[EPV]; } u;
+            u.raw = reinterpret_cast<const V*>(p)[i];
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) r.e[i * EPV + j] = u.e[j];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < K; ++k) r.e[k] = k < nv ? p[k] : from_f32<T>(0.0f);
+    }
+    return r;
+}
+template <typename T, int K>
+__device__ __forceinline__ void unpack(const RawK<T, K>& r, float (&v)[K]) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = to_f32<T>(r.e[k]);
+}
+
+// Branch-free forms for kernels whose host dispatch guarantees 16-byte-aligned rows and a sequence
+// length that is a multiple of K: a lane is either fully inside the row (pred) or fully outside.
+template <typename T, int K>
+__device__ __forceinline__ RawK<T, K> load_vec(const T* __restrict__ p, bool pred) {
+    constexpr int BYTES = K * (int)sizeof(T);
+    constexpr int VB = BYTES >= 16 ? 16 : BYTES;
+    constexpr int NV = BYTES / VB;
+    using V = typename Pack<T, VB>::type;
+    union { V raw[NV]; RawK<T, K> r; } u;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) u.raw[i] = V(0);
+    if (pred) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) u.raw[i] = reinterpret_cast<const V*>(p)[i];
+    }
+    return u.r;
+}
+template <typename T, int K>
+__device__ __forceinline__ void store_vec(T* __restrict__ p, bool pred, const float (&v)[K]) {
+    constexpr int BYTES = K * (int)sizeof(T);
+    constexpr int VB = BYTES >= 16 ? 16 : BYTES;
+    constexpr int NV = BYTES / VB;
+    using V = typename Pack<T, VB>::type;
+    union { V raw[NV]; T e[K]; } u;
+#pragma unroll
+    for (int k = 0; k < K; ++k) u.e[k] = from_f32<T>(v[k]);
+    if (pred) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) reinterpret_cast<V*>(p)[i] = u.raw[i];
+    }
+}
+
+// Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain the
+// wave's outstanding global loads/stores (hipcc emits s_waitcnt vmcnt(0) for those).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// ---- in-kernel stamps: DIAGNOSTIC builds only (tools/scan_lab.hip defines VIVIM_STAMPS) ----
+#ifdef VIVIM_STAMPS
+__device__ unsigned long long* g_stamp_buf = nullptr;   // [block][wave][step][slot]
+constexpr int kStampSlots = 16, kStampSteps = 8, kStampWaves = 8;
+__device__ __forceinline__ void stamp(int step, int slot, int wave, int lane) {
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (g_stamp_buf && lane == 0 && step < kStampSteps && blockIdx.x < 2 && blockIdx.y == 0)
+        g_stamp_buf[((blockIdx.x * kStampWaves + wave) * kStampSteps + step) * kStampSlots + slot] = t;
+}
+#define VIVIM_STAMP(step, slot, wave, lane) stamp(step, slot, wave, lane)
+#else
+#define VIVIM_STAMP(step, slot, wave, lane) ((void)0)
+#endif
+
 // ---- wave64 scans of affine maps  x -> P*x + H  ----
 // Forward: lane l ends up with the composition of lanes 0..l (lane 0 applied first).
 __device__ __forceinline__ void wave_scan_affine_fwd(float& P, float& H, int lane) {
@@ -109,6 +197,38 @@ __device__ __forceinline__ void wave_scan_affine_rev(float& P, float& H, int lan
             P = P * Pn;
         }
     }
+}
+
+// ---- DPP forms (no LDS crossbar): row_shr 1/2/4/8 inside 16-lane rows, then row_bcast 15 / 31 ----
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_mov(float old, float src) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float read_lane(float v, int lane) {   // wave-uniform result (SGPR)
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+constexpr int kDppWaveShr1 = 0x138;   // lane l <- lane l-1 (lane 0 keeps `old`)
+constexpr int kDppWaveShl1 = 0x130;   // lane l <- lane l+1 (lane 63 keeps `old`)
+
+// Two independent forward scans of affine maps, interleaved so that every DPP read of a VGPR is at
+// least two instructions behind its last VALU write (the gfx9 DPP hazard the compiler cannot see
+// inside asm); the leading s_nop covers the compiler-generated producer.  Lanes without a source
+// (row start, masked rows) are not written, i.e. they compose with the identity.  Needs EXEC = all ones.
+#define VIVIM_SCAN2_STEP(ctrl)                                   \
+    "v_fmac_f32_dpp %0, %0, %2 " ctrl " bank_mask:0xf\n\t"      \
+    "v_fmac_f32_dpp %1, %1, %3 " ctrl " bank_mask:0xf\n\t"      \
+    "v_mul_f32_dpp %2, %2, %2 " ctrl " bank_mask:0xf\n\t"       \
+    "v_mul_f32_dpp %3, %3, %3 " ctrl " bank_mask:0xf\n\t"
+__device__ __forceinline__ void wave_scan2_affine_fwd(float& P0, float& H0, float& P1, float& H1) {
+    asm volatile("s_nop 1\n\t"
+                 VIVIM_SCAN2_STEP("row_shr:1 row_mask:0xf")
+                 VIVIM_SCAN2_STEP("row_shr:2 row_mask:0xf")
+                 VIVIM_SCAN2_STEP("row_shr:4 row_mask:0xf")
+                 VIVIM_SCAN2_STEP("row_shr:8 row_mask:0xf")
+                 VIVIM_SCAN2_STEP("row_bcast:15 row_mask:0xa")
+                 VIVIM_SCAN2_STEP("row_bcast:31 row_mask:0xc")
+                 "s_nop 1"
+                 : "+v"(H0), "+v"(H1), "+v"(P0), "+v"(P1));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

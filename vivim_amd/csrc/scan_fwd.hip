@@ -4,15 +4,26 @@
 //   d_t = softplus(delta_t + bias);  h_{n,t} = exp(d_t A_n) h_{n,t-1} + d_t u_t B_{n,t}
 //   out_t = sum_n C_{n,t} h_{n,t} + D u_t;   out_z_t = out_t * silu(z_t)
 //
-// Mapping (NOT the reference's one-block-per-(batch,channel) BlockScan):
-//   * a WAVE owns R channels of one batch element and walks the token axis in steps of 64*K tokens;
-//     lane l holds tokens [l*K, l*K+K) of the step in registers, so u / delta / z / out / out_z move as
-//     one 16-byte access per lane and B_n / C_n rows are loaded once and reused by the R channels;
-//   * per (channel, n): a K-long in-register scan, one wave64 scan of the lane aggregates (affine maps
-//     h -> P h + H), and the running state between steps lives in a per-wave LDS row -- waves never
-//     talk to each other, so the kernel has no barrier;
-//   * the state after every step is written to `x` (batch, dim, n_chunks, dstate): the backward's
-//     forward re-scan restarts from it (role of the reference's x, selective_scan.cpp:307-313).
+// Two kernels (NOT the reference's one-block-per-(batch,channel) BlockScan):
+//
+// ssm_fwd_nsplit_kernel -- the fast path (variable B/C, dstate a multiple of 8).
+//   * a WORKGROUP owns R=2 channels of one batch element and walks the token axis in steps of 64*K
+//     tokens; its NS waves all see the same tokens but each owns SPW = N/NS states, so the serial
+//     recurrence along L costs nothing in parallelism: B*(D/2)*NS waves are in flight (the reference:
+//     B*D blocks, serial in L) and no cross-workgroup carry exists;
+//   * lane l holds tokens [l*K, l*K+K) of the step.  softplus(delta+bias), delta*u and the D*u term are
+//     computed ONCE per token by the whole workgroup (R*K/NS tokens per thread) and shared through LDS;
+//     each wave accumulates sum_n C h over its own states in registers and adds it into the y tile in
+//     LDS (ds_add_f32); the epilogue (z gate, out/out_z stores) is again spread over all threads;
+//   * per (state, channel pair): K-long in-register recurrence giving the lane's affine map h -> P h + H,
+//     one wave64 scan of the 64 maps done with DPP row operations (two channels interleaved, no LDS
+//     crossbar, no nops), carry between steps in registers;
+//   * the state after every step goes to `x` (batch, dim, n_chunks, dstate): the backward's forward
+//     re-scan restarts from it (role of the reference's x, selective_scan.cpp:307-313).
+//
+// ssm_fwd_generic_kernel -- any dstate, constant B/C: a wave owns R channels and ALL states (carry in a
+//   per-wave LDS row, shuffle-based scan); slower, used only off Vivim's path.
+#include <stdlib.h>
 #include "common.cuh"
 
 namespace vivim {
@@ -20,7 +31,7 @@ namespace vivim {
 constexpr int kScanWaves = 4;   // waves per workgroup (independent of each other)
 
 template <typename T, int K, int R, bool HAS_Z, bool VAR_BC>
-__global__ void __launch_bounds__(kScanWaves * kWave) ssm_fwd_kernel(const vivim_ssm_fwd_params p) {
+__global__ void __launch_bounds__(kScanWaves * kWave) ssm_fwd_generic_kernel(const vivim_ssm_fwd_params p) {
     constexpr int TILE = kWave * K;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -138,6 +149,272 @@ __global__ void __launch_bounds__(kScanWaves * kWave) ssm_fwd_kernel(const vivim
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+constexpr int kNsR = 2;            // channels per workgroup
+constexpr int kLdsRow = 65;        // [slot][k][lane] tiles, rows padded to 65 floats: conflict-free both ways
+
+template <typename T, int K, int NS, bool HAS_Z, int MINW>
+__global__ void __launch_bounds__(NS * kWave, MINW) ssm_fwd_nsplit_kernel(const vivim_ssm_fwd_params p) {
+    constexpr int R = kNsR;
+    constexpr int TILE = kWave * K;
+    constexpr int NT = NS * kWave;
+    constexpr int IPT = R * TILE / NT;                 // tokens per thread in the shared prologue / epilogue
+    static_assert(R * TILE % NT == 0 && IPT >= 1 && K % IPT == 0, "bad tiling");
+    constexpr int TSZ = R * K * kLdsRow;               // floats per [r][k][lane] tile
+    __shared__ float s_dl[TSZ];                        // softplus(delta + bias)   (0 on padded tokens)
+    __shared__ float s_w[TSZ];                         // delta * u
+    __shared__ float s_du[TSZ];                        // D * u
+    __shared__ float s_part[NS * TSZ];                 // per-wave partial sum_n C h (summed in fixed order)
+    __shared__ float s_carry[256 * R];                 // running state h[n][r] between steps (wave-private rows)
+    __shared__ float s_A2[256 * R];                    // A[d][n] * log2(e)                    (wave-private rows)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: A / carry go scalar
+    const int b = blockIdx.y;
+    const int N = p.dstate, L = p.seqlen;
+    const int cpg = p.dim / p.n_groups;
+    const int wpg = (cpg + R - 1) / R;
+    const int g = blockIdx.x / wpg;
+    const int d0 = g * cpg + (blockIdx.x - g * wpg) * R;
+    const int nvalid = min(R, (g + 1) * cpg - d0);
+    const int SPW = N / NS;                            // states owned by this wave: [n0, n0 + SPW)
+    const int n0 = wave * SPW;
+    const int nsteps = (L + TILE - 1) / TILE;
+    constexpr int CPS = TILE / kChunk;                 // checkpoint rows per step
+    constexpr int LPC = kChunk / K;                    // lanes per checkpoint chunk
+    const int nck = (L + kChunk - 1) / kChunk;
+
+    // ---- this thread's slice of the shared per-token work ----
+    const int i0 = tid * IPT;
+    const int pr = i0 / TILE;                          // channel slot
+    const int ptok = i0 - pr * TILE;                   // first token inside the tile
+    const int plane = ptok / K, pj = ptok - plane * K; // where those tokens live in the [k][lane] tiles
+    const int pd = d0 + min(pr, nvalid - 1);
+    const float pD = p.D ? static_cast<const float*>(p.D)[pd] : 0.0f;
+    const float pbias = p.delta_bias ? static_cast<const float*>(p.delta_bias)[pd] : 0.0f;
+    const T* __restrict__ pu = static_cast<const T*>(p.u) + b * p.u_batch_stride + pd * p.u_d_stride;
+    const T* __restrict__ pdl = static_cast<const T*>(p.delta) + b * p.delta_batch_stride + pd * p.delta_d_stride;
+    const T* __restrict__ pz = HAS_Z ? static_cast<const T*>(p.z) + b * p.z_batch_stride + pd * p.z_d_stride : nullptr;
+    T* __restrict__ pout = static_cast<T*>(p.out) + b * p.out_batch_stride + pd * p.out_d_stride;
+    T* __restrict__ poutz = HAS_Z ? static_cast<T*>(p.out_z) + b * p.out_z_batch_stride + pd * p.out_z_d_stride : nullptr;
+    const int pbase = (pr * K + pj) * kLdsRow + plane;
+
+    // per-token work of one step from raw u / delta: writes the three shared tiles
+    auto prologue = [&](int step, const RawK<T, IPT>& ur, const RawK<T, IPT>& dr) {
+        const bool pin = step * TILE + ptok < L;
+        float uf[IPT], df[IPT];
+        unpack(ur, uf);
+        unpack(dr, df);
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            const float raw = df[i] + pbias;
+            const float sp = p.delta_softplus ? softplus_ref(raw) : raw;
+            const float dlv = pin ? sp : 0.0f;          // padded tokens: exp2(0)=1 and drive 0 -> identity map
+            s_dl[pbase + i * kLdsRow] = dlv;
+            s_w[pbase + i * kLdsRow] = dlv * uf[i];
+            s_du[pbase + i * kLdsRow] = pD * uf[i];
+        }
+    };
+
+    const float* __restrict__ A = static_cast<const float*>(p.A);
+    const T* __restrict__ Bv = static_cast<const T*>(p.B) + b * p.B_batch_stride + g * p.B_group_stride;
+    const T* __restrict__ Cv = static_cast<const T*>(p.C) + b * p.C_batch_stride + g * p.C_group_stride;
+    float* __restrict__ xck = static_cast<float*>(p.x);
+    int d[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) d[r] = d0 + min(r, nvalid - 1);
+    for (int i = lane; i < SPW * R; i += kWave) {
+        const int n = n0 + i / R, r = i - (i / R) * R;
+        s_carry[n0 * R + i] = 0.0f;
+        s_A2[n0 * R + i] = A[d[r] * p.A_d_stride + n * p.A_dstate_stride] * kLog2e;      // fwd_kernel.cuh:168-175
+    }
+    // B/C rows of the first two states of the NEXT step are fetched one step ahead (Bq/Cq)
+    RawK<T, K> Bq[2], Cq[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const bool ok = lane * K < L && i < SPW;
+        Bq[i] = load_vec<T, K>(Bv + (n0 + i) * p.B_dstate_stride + lane * K, ok);
+        Cq[i] = load_vec<T, K>(Cv + (n0 + i) * p.C_dstate_stride + lane * K, ok);
+    }
+
+    // host dispatch guarantees aligned rows and L % K == 0: lanes / threads are all-in or all-out
+    prologue(0, load_vec<T, IPT>(pu + ptok, ptok < L), load_vec<T, IPT>(pdl + ptok, ptok < L));
+    lds_barrier();
+    for (int step = 0; step < nsteps; ++step) {
+        const int t0 = step * TILE + lane * K;
+        VIVIM_STAMP(step, 0, wave, lane);
+        // ---- issue every global load of this step up front; they are consumed after LDS/VALU work ----
+        const int tp = step * TILE + ptok;             // this thread's epilogue tokens
+        const int tn = tp + TILE;                      // ... and next step's prologue tokens
+        RawK<T, IPT> zr, unx, dnx;
+        if (HAS_Z) zr = load_vec<T, IPT>(pz + tp, tp < L);
+        const bool more = step + 1 < nsteps;
+        unx = load_vec<T, IPT>(pu + tn, tn < L);
+        dnx = load_vec<T, IPT>(pdl + tn, tn < L);
+        const bool in = t0 < L;
+
+        float dl[R][K], w[R][K], yp[R][K], dsum[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            dsum[r] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                dl[r][k] = s_dl[(r * K + k) * kLdsRow + lane];
+                w[r][k] = s_w[(r * K + k) * kLdsRow + lane];
+                yp[r][k] = 0.0f;
+                dsum[r] += dl[r][k];
+            }
+        }
+        // the rows prefetched one step ago become current; only now do we depend on vmcnt (the LDS reads
+        // above were issued first), then the next step's first two states are requested
+        RawK<T, K> Bc[2] = {Bq[0], Bq[1]}, Cc[2] = {Cq[0], Cq[1]};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool ok = t0 + TILE < L && i < SPW;
+            Bq[i] = load_vec<T, K>(Bv + (n0 + i) * p.B_dstate_stride + t0 + TILE, ok);
+            Cq[i] = load_vec<T, K>(Cv + (n0 + i) * p.C_dstate_stride + t0 + TILE, ok);
+        }
+        VIVIM_STAMP(step, 1, wave, lane);
+        // one state for the wave's R channels: lane maps, DPP scan, apply, checkpoint
+        auto do_state = [&](int n, const RawK<T, K>& Braw, const RawK<T, K>& Craw) {
+            float A2[R], cin[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                A2[r] = s_A2[n * R + r];
+                cin[r] = s_carry[n * R + r];
+            }
+            float Bn[K], Cn[K];
+            unpack(Braw, Bn);
+            unpack(Craw, Cn);
+            // lane map h -> P h + H over its K tokens: P = exp2(A2 * sum_k delta_k), H by the recurrence
+            float a[R][K], P[R], H[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                P[r] = fast_exp2(dsum[r] * A2[r]);
+                H[r] = 0.0f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    a[r][k] = fast_exp2(dl[r][k] * A2[r]);
+                    H[r] = fmaf(a[r][k], H[r], w[r][k] * Bn[k]);
+                }
+            }
+            wave_scan2_affine_fwd(P[0], H[0], P[1], H[1]);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float hend = fmaf(P[r], cin[r], H[r]);                 // state after this lane's last token
+                float h = dpp_mov<kDppWaveShr1>(cin[r], hend);               // state entering this lane
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    h = fmaf(a[r][k], h, w[r][k] * Bn[k]);
+                    yp[r][k] = fmaf(h, Cn[k], yp[r][k]);
+                }
+#pragma unroll
+                for (int q = 0; q < CPS; ++q) {                              // state after every kChunk tokens
+                    const float v = read_lane(hend, (q + 1) * LPC - 1);
+                    const int row = step * CPS + q;
+                    if (lane == 0 && r < nvalid && row < nck)
+                        xck[(((int64_t)b * p.dim + d[r]) * nck + row) * N + n] = v;
+                    if (q == CPS - 1) {                                      // state after the step
+                        wave_lds_fence();
+                        if (lane == 0) s_carry[n * R + r] = v;
+                        wave_lds_fence();
+                    }
+                }
+            }
+        };
+        do_state(n0, Bc[0], Cc[0]);
+        VIVIM_STAMP(step, 2, wave, lane);
+        if (SPW > 1) {
+            RawK<T, K> Bx = load_vec<T, K>(Bv + (n0 + 2) * p.B_dstate_stride + t0, in && SPW > 2);
+            RawK<T, K> Cx = load_vec<T, K>(Cv + (n0 + 2) * p.C_dstate_stride + t0, in && SPW > 2);
+            do_state(n0 + 1, Bc[1], Cc[1]);
+#pragma unroll 1
+            for (int n = n0 + 2; n < n0 + SPW; ++n) {
+                const RawK<T, K> Bn_ = Bx, Cn_ = Cx;
+                const bool nx = in && (n + 1 < n0 + SPW);
+                Bx = load_vec<T, K>(Bv + (n + 1) * p.B_dstate_stride + t0, nx);   // flies during this state
+                Cx = load_vec<T, K>(Cv + (n + 1) * p.C_dstate_stride + t0, nx);
+                do_state(n, Bn_, Cn_);
+            }
+        }
+        VIVIM_STAMP(step, 3, wave, lane);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int k = 0; k < K; ++k) s_part[wave * TSZ + (r * K + k) * kLdsRow + lane] = yp[r][k];
+        VIVIM_STAMP(step, 4, wave, lane);
+        lds_barrier();
+        VIVIM_STAMP(step, 5, wave, lane);
+        // ---- epilogue of this step + prologue of the next, same token slice per thread ----
+        {
+            float y[IPT];
+#pragma unroll
+            for (int i = 0; i < IPT; ++i) {
+                float acc = s_du[pbase + i * kLdsRow];
+#pragma unroll
+                for (int wv = 0; wv < NS; ++wv) acc += s_part[wv * TSZ + pbase + i * kLdsRow];   // fixed order
+                y[i] = acc;
+            }
+            if (pr < nvalid) {
+                store_vec<T, IPT>(pout + tp, tp < L, y);
+                if (HAS_Z) {
+                    float zf[IPT];
+                    unpack(zr, zf);
+#pragma unroll
+                    for (int i = 0; i < IPT; ++i) y[i] *= zf[i] * sigmoidf_fast(zf[i]);       // fwd_kernel.cuh:290
+                    store_vec<T, IPT>(poutz + tp, tp < L, y);
+                }
+            }
+        }
+        VIVIM_STAMP(step, 6, wave, lane);
+        if (more) prologue(step + 1, unx, dnx);
+        VIVIM_STAMP(step, 7, wave, lane);
+        lds_barrier();
+        VIVIM_STAMP(step, 8, wave, lane);
+    }
+}
+
+template <typename T, int K, int NS, int MINW>
+static void launch_fwd_nsplit(const vivim_ssm_fwd_params& p, hipStream_t stream) {
+    const int cpg = p.dim / p.n_groups;
+    dim3 grid(((cpg + kNsR - 1) / kNsR) * p.n_groups, p.batch);
+    if (p.z) hipLaunchKernelGGL((ssm_fwd_nsplit_kernel<T, K, NS, true, MINW>), grid, dim3(NS * kWave), 0, stream, p);
+    else     hipLaunchKernelGGL((ssm_fwd_nsplit_kernel<T, K, NS, false, MINW>), grid, dim3(NS * kWave), 0, stream, p);
+}
+
+// 8 waves per workgroup, dstate / 8 states per wave.  VIVIM_FWD_VARIANT (tuning only) picks the tiling.
+template <typename T>
+static bool try_fwd_nsplit(const vivim_ssm_fwd_params& p, hipStream_t stream) {
+    if (!p.is_variable_B || !p.is_variable_C || p.dstate % 8 != 0) return false;
+    // the fast kernel uses unconditional 16-byte vectors: every row must be 16-byte aligned and the
+    // sequence a whole number of 8-token lanes; anything else takes the generic kernel.
+    const int64_t epv = 16 / (int64_t)sizeof(T);
+    auto al = [&](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    auto st = [&](int64_t e) { return e % epv == 0; };
+    if (p.seqlen % 8 != 0 || !al(p.u) || !al(p.delta) || !al(p.B) || !al(p.C) || !al(p.out) ||
+        !st(p.u_batch_stride) || !st(p.u_d_stride) || !st(p.delta_batch_stride) || !st(p.delta_d_stride) ||
+        !st(p.out_batch_stride) || !st(p.out_d_stride) || !st(p.B_batch_stride) || !st(p.B_group_stride) ||
+        !st(p.B_dstate_stride) || !st(p.C_batch_stride) || !st(p.C_group_stride) || !st(p.C_dstate_stride))
+        return false;
+    if (p.z && (!al(p.z) || !al(p.out_z) || !st(p.z_batch_stride) || !st(p.z_d_stride) ||
+                !st(p.out_z_batch_stride) || !st(p.out_z_d_stride)))
+        return false;
+    static const int forced = [] { const char* e = getenv("VIVIM_FWD_VARIANT"); return e ? atoi(e) : 0; }();
+    // 512-token steps (K=8) halve the per-step fixed cost; 256-token steps (K=4) need 100 instead of 160 VGPRs,
+    // so several workgroups share a CU -- better once there are enough workgroups to fill the chip twice.
+    const int64_t nwg = (int64_t)((p.dim / p.n_groups + kNsR - 1) / kNsR) * p.n_groups * p.batch;
+    int variant = forced ? forced : (nwg >= 512 ? 2 : 1);
+    switch (variant) {
+        case 2:  launch_fwd_nsplit<T, 4, 8, 2>(p, stream); break;     // K=4
+        case 3:  return false;                                         // generic kernel (tuning only)
+        case 4:  launch_fwd_nsplit<T, 8, 8, 4>(p, stream); break;     // K=8 capped at 128 VGPRs (tuning only)
+        default: launch_fwd_nsplit<T, 8, 8, 2>(p, stream); break;     // K=8
+    }
+    return true;
+}
+
 template <typename T, int K, int R>
 static void launch_fwd(const vivim_ssm_fwd_params& p, hipStream_t stream) {
     const int cpg = p.dim / p.n_groups;
@@ -146,23 +423,24 @@ static void launch_fwd(const vivim_ssm_fwd_params& p, hipStream_t stream) {
     const size_t smem = (size_t)kScanWaves * R * p.dstate * sizeof(float);
     const bool var = p.is_variable_B;   // capi enforces is_variable_B == is_variable_C
     if (p.z) {
-        if (var) hipLaunchKernelGGL((ssm_fwd_kernel<T, K, R, true, true>), grid, dim3(kScanWaves * kWave), smem, stream, p);
-        else     hipLaunchKernelGGL((ssm_fwd_kernel<T, K, R, true, false>), grid, dim3(kScanWaves * kWave), smem, stream, p);
+        if (var) hipLaunchKernelGGL((ssm_fwd_generic_kernel<T, K, R, true, true>), grid, dim3(kScanWaves * kWave), smem, stream, p);
+        else     hipLaunchKernelGGL((ssm_fwd_generic_kernel<T, K, R, true, false>), grid, dim3(kScanWaves * kWave), smem, stream, p);
     } else {
-        if (var) hipLaunchKernelGGL((ssm_fwd_kernel<T, K, R, false, true>), grid, dim3(kScanWaves * kWave), smem, stream, p);
-        else     hipLaunchKernelGGL((ssm_fwd_kernel<T, K, R, false, false>), grid, dim3(kScanWaves * kWave), smem, stream, p);
+        if (var) hipLaunchKernelGGL((ssm_fwd_generic_kernel<T, K, R, false, true>), grid, dim3(kScanWaves * kWave), smem, stream, p);
+        else     hipLaunchKernelGGL((ssm_fwd_generic_kernel<T, K, R, false, false>), grid, dim3(kScanWaves * kWave), smem, stream, p);
     }
 }
 
-// tokens per checkpoint row of x: 64 lanes * K tokens.  K = 4 for every dtype in this build so that the
-// forward's and the backward's steps coincide.
-int scan_chunk_len(int) { return kWave * 4; }
+// tokens per checkpoint row of x: the generic kernel (K=4) writes one row per 256-token step, the n-split
+// kernel (K=8, 512-token steps) two.
+int scan_chunk_len(int) { return kChunk; }
+static_assert(kWave * 4 == kChunk, "generic kernel step must equal the checkpoint chunk");
 
 bool ssm_fwd_dispatch(const vivim_ssm_fwd_params& p, hipStream_t s) {
     switch (p.itype) {
-        case VIVIM_F32: launch_fwd<float, 4, 2>(p, s); return true;
-        case VIVIM_F16: launch_fwd<f16_t, 4, 2>(p, s); return true;
-        case VIVIM_BF16: launch_fwd<bf16_t, 4, 2>(p, s); return true;
+        case VIVIM_F32: if (!try_fwd_nsplit<float>(p, s)) launch_fwd<float, 4, 2>(p, s); return true;
+        case VIVIM_F16: if (!try_fwd_nsplit<f16_t>(p, s)) launch_fwd<f16_t, 4, 2>(p, s); return true;
+        case VIVIM_BF16: if (!try_fwd_nsplit<bf16_t>(p, s)) launch_fwd<bf16_t, 4, 2>(p, s); return true;
     }
     return false;
 }
