@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define VIVIM_ABI_VERSION 1
+#define VIVIM_ABI_VERSION 2
 
 typedef enum { VIVIM_F32 = 0, VIVIM_F16 = 1, VIVIM_BF16 = 2 } vivim_dtype_t;
 
@@ -100,6 +100,10 @@ typedef struct {
     void *dB, *dC;              /* f32, pre-zeroed: (batch, n_groups, dstate, seqlen) if variable else (dim, dstate) */
     void *dD;                   /* (dim) f32 pre-zeroed, or NULL iff D == NULL */
     void *ddelta_bias;          /* (dim) f32 pre-zeroed, or NULL iff delta_bias == NULL */
+    void *workspace;            /* device scratch of >= vivim_scan_bwd_workspace_bytes() bytes, or NULL: the
+                                   kernel then walks the whole sequence inside one workgroup per 16 channels
+                                   (correct, but far fewer workgroups in flight).  Contents are don't-care. */
+    int64_t workspace_bytes;
 } vivim_ssm_bwd_params;
 
 /* ---- causal depthwise conv1d (causal_conv1d.h:9-52) ------------------------------------------ */
@@ -138,6 +142,10 @@ size_t vivim_sizeof(int which);
 
 /* Tokens per checkpoint row of `x` for an input dtype; n_chunks = ceil(seqlen / chunk_len). */
 int vivim_scan_chunk_len(int itype);
+
+/* Scratch the backward wants for splitting the token axis over workgroups (carries of the reverse
+ * recurrence per (batch, channel, segment, state)); depends only on the sizes in `f`. */
+size_t vivim_scan_bwd_workspace_bytes(const vivim_ssm_fwd_params *f);
 
 int vivim_selective_scan_fwd(const vivim_ssm_fwd_params *p, void *stream);
 int vivim_selective_scan_bwd(const vivim_ssm_bwd_params *p, void *stream);

@@ -29,7 +29,7 @@ def test_struct_layouts_match():
     for which, st in enumerate((_lib.SsmFwdParams, _lib.SsmBwdParams, _lib.ConvFwdParams, _lib.ConvBwdParams)):
         assert L.vivim_sizeof(which) == ctypes.sizeof(st)
     assert L.vivim_sizeof(99) == 0
-    assert L.vivim_abi_version() == 1
+    assert L.vivim_abi_version() == 2
     assert L.vivim_scan_chunk_len(_lib.F32) > 0 and L.vivim_scan_chunk_len(_lib.BF16) % 64 == 0
 
 

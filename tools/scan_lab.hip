@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <vector>
 #include "../vivim_amd/csrc/scan_fwd.hip"
+#include "../vivim_amd/csrc/scan_bwd.hip"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
@@ -69,5 +70,47 @@ int main(int argc, char** argv) {
                 printf("  total=%lld\n", (long long)(s[8] - s[0]));
             }
         }
+    if (argc > 5 && atoi(argv[5]) == 1) {   // ---- backward ----
+        unsigned short *dout, *du, *ddl, *dz;
+        float *dA, *dB, *dC, *dD, *dbias;
+        CK(hipMalloc(&dout, nact * 2)); CK(hipMalloc(&du, nact * 2)); CK(hipMalloc(&ddl, nact * 2)); CK(hipMalloc(&dz, nact * 2));
+        CK(hipMemcpy(dout, h.data(), nact * 2, hipMemcpyHostToDevice));
+        CK(hipMalloc(&dA, D * N * 4)); CK(hipMalloc(&dB, nbc * 4)); CK(hipMalloc(&dC, nbc * 4)); CK(hipMalloc(&dD, D * 4)); CK(hipMalloc(&dbias, D * 4));
+        CK(hipMemset(dA, 0, D * N * 4)); CK(hipMemset(dB, 0, nbc * 4)); CK(hipMemset(dC, 0, nbc * 4)); CK(hipMemset(dD, 0, D * 4)); CK(hipMemset(dbias, 0, D * 4));
+        vivim_ssm_bwd_params q = {};
+        q.f = p; q.f.out_z = nullptr;
+        q.dout_batch_stride = q.du_batch_stride = q.ddelta_batch_stride = q.dz_batch_stride = (int64_t)D * L;
+        q.dout_d_stride = q.du_d_stride = q.ddelta_d_stride = q.dz_d_stride = L;
+        q.dA_d_stride = N; q.dA_dstate_stride = 1;
+        q.dB_batch_stride = q.dC_batch_stride = (int64_t)N * L; q.dB_group_stride = q.dC_group_stride = (int64_t)N * L;
+        q.dB_dstate_stride = q.dC_dstate_stride = L;
+        q.dout = dout; q.du = du; q.ddelta = ddl; q.dz = dz; q.dA = dA; q.dB = dB; q.dC = dC; q.dD = dD; q.ddelta_bias = dbias;
+        if (argc > 6 && atoi(argv[6]) == 1) {
+            q.workspace_bytes = (int64_t)vivim::scan_bwd_workspace_bytes(q.f);
+            if (q.workspace_bytes) CK(hipMalloc(&q.workspace, q.workspace_bytes));
+            printf("workspace %lld bytes\n", (long long)q.workspace_bytes);
+        }
+        CK(hipMemset(dbg, 0, nstamp * 8));
+        vivim::ssm_bwd_dispatch(q, 0);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < 3; ++i) vivim::ssm_bwd_dispatch(q, 0);
+        CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("BWD B=%d D=%d L=%d N=%d: %.1f us per launch (stamped)\n", B, D, L, N, ms * 1e3 / 3);
+        CK(hipMemcpy(hs.data(), dbg, nstamp * 8, hipMemcpyDeviceToHost));
+        const char* bn[] = {"loads+prep", "n0", "n1", "n2", "n3", "n4..15", "barrier", "flush", "barrier2", "outputs"};
+        for (int w = 0; w < vivim::kStampWaves; w += 7) {
+            printf("bwd block 0 wave %d:\n", w);
+            for (int st = 1; st < 5; ++st) {
+                const unsigned long long* s = &hs[((0 * vivim::kStampWaves + w) * vivim::kStampSteps + st) * vivim::kStampSlots];
+                printf("  step %d:", st);
+                for (int k = 0; k < 10; ++k) printf(" %s=%lld", bn[k], (long long)(s[k + 1] - s[k]));
+                printf("  total=%lld\n", (long long)(s[10] - s[0]));
+                printf("      inside n=1: unpack+prefetch=%lld rec-read=%lld fwd=%lld rev+outputs=%lld lds-add=%lld\n",
+                       (long long)(s[11] - s[2]), (long long)(s[12] - s[11]), (long long)(s[13] - s[12]), (long long)(s[14] - s[13]), (long long)(s[15] - s[14]));
+            }
+        }
+    }
     return 0;
 }

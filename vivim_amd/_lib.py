@@ -37,7 +37,8 @@ class SsmBwdParams(ctypes.Structure):
                               "dA_d_stride", "dA_dstate_stride",
                               "dB_batch_stride", "dB_group_stride", "dB_dstate_stride",
                               "dC_batch_stride", "dC_group_stride", "dC_dstate_stride")]
-        + [(n, vp) for n in ("dout", "du", "ddelta", "dz", "dA", "dB", "dC", "dD", "ddelta_bias")]
+        + [(n, vp) for n in ("dout", "du", "ddelta", "dz", "dA", "dB", "dC", "dD", "ddelta_bias", "workspace")]
+        + [("workspace_bytes", i64)]
     )
 
 
@@ -62,6 +63,7 @@ class ConvBwdParams(ctypes.Structure):
 
 
 EXPORTS = ("vivim_abi_version", "vivim_last_error", "vivim_scan_chunk_len", "vivim_sizeof",
+           "vivim_scan_bwd_workspace_bytes",
            "vivim_selective_scan_fwd", "vivim_selective_scan_bwd",
            "vivim_causal_conv1d_fwd", "vivim_causal_conv1d_bwd")
 
@@ -88,12 +90,14 @@ def lib():
         L.vivim_last_error.restype = ctypes.c_char_p
         L.vivim_sizeof.restype = ctypes.c_size_t
         L.vivim_sizeof.argtypes = [ctypes.c_int]
+        L.vivim_scan_bwd_workspace_bytes.restype = ctypes.c_size_t
+        L.vivim_scan_bwd_workspace_bytes.argtypes = [ctypes.POINTER(SsmFwdParams)]
         for name, st in (("vivim_selective_scan_fwd", SsmFwdParams), ("vivim_selective_scan_bwd", SsmBwdParams),
                          ("vivim_causal_conv1d_fwd", ConvFwdParams), ("vivim_causal_conv1d_bwd", ConvBwdParams)):
             fn = getattr(L, name)
             fn.argtypes = [ctypes.POINTER(st), vp]
             fn.restype = ctypes.c_int
-        if L.vivim_abi_version() != 1:
+        if L.vivim_abi_version() != 2:
             raise ImportError("libvivim_hip.so ABI version mismatch")
         for which, st in enumerate((SsmFwdParams, SsmBwdParams, ConvFwdParams, ConvBwdParams)):
             if L.vivim_sizeof(which) != ctypes.sizeof(st):

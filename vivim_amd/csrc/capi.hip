@@ -12,6 +12,7 @@ bool conv_bwd_dispatch(const vivim_conv_bwd_params&, hipStream_t);
 bool ssm_fwd_dispatch(const vivim_ssm_fwd_params&, hipStream_t);
 bool ssm_bwd_dispatch(const vivim_ssm_bwd_params&, hipStream_t);
 int scan_chunk_len(int itype);
+size_t scan_bwd_workspace_bytes(const vivim_ssm_fwd_params&);
 }  // namespace vivim
 
 static thread_local char g_err[512] = "";
@@ -62,6 +63,9 @@ extern "C" {
 int vivim_abi_version(void) { return VIVIM_ABI_VERSION; }
 const char* vivim_last_error(void) { return g_err; }
 int vivim_scan_chunk_len(int itype) { return vivim::scan_chunk_len(itype); }
+size_t vivim_scan_bwd_workspace_bytes(const vivim_ssm_fwd_params* f) {
+    return f ? vivim::scan_bwd_workspace_bytes(*f) : 0;
+}
 size_t vivim_sizeof(int which) {
     switch (which) {
         case 0: return sizeof(vivim_ssm_fwd_params);

@@ -231,6 +231,44 @@ __device__ __forceinline__ void wave_scan2_affine_fwd(float& P0, float& H0, floa
                  : "+v"(H0), "+v"(H1), "+v"(P0), "+v"(P1));
 }
 
+// Reverse direction: in-row part with row_shl (lane l combines with lanes l+1.. of its 16-lane row);
+// rows are joined afterwards by wave_scan2_rev_join (there is no reverse row_bcast).
+#define VIVIM_SCAN2_STEP_L(ctrl) VIVIM_SCAN2_STEP(ctrl)
+__device__ __forceinline__ void wave_scan2_affine_rev_rows(float& P0, float& H0, float& P1, float& H1) {
+    asm volatile("s_nop 1\n\t"
+                 VIVIM_SCAN2_STEP("row_shl:1 row_mask:0xf")
+                 VIVIM_SCAN2_STEP("row_shl:2 row_mask:0xf")
+                 VIVIM_SCAN2_STEP("row_shl:4 row_mask:0xf")
+                 VIVIM_SCAN2_STEP("row_shl:8 row_mask:0xf")
+                 "s_nop 1"
+                 : "+v"(H0), "+v"(H1), "+v"(P0), "+v"(P1));
+}
+// After the in-row scan lane 16r holds row r's total map.  Compose, for every lane, the maps of the rows
+// to its right (rows r+1..3) and apply its own after them: lane l ends with the composition of lanes l..63.
+__device__ __forceinline__ void wave_scan_rev_join(float& P, float& H, int lane) {
+    const float p1 = read_lane(P, 16), h1 = read_lane(H, 16);
+    const float p2 = read_lane(P, 32), h2 = read_lane(H, 32);
+    const float p3 = read_lane(P, 48), h3 = read_lane(H, 48);
+    const float q2p = p2 * p3, q2h = fmaf(p2, h3, h2);          // rows 2..3
+    const float q1p = p1 * q2p, q1h = fmaf(p1, q2h, h1);        // rows 1..3
+    const int row = lane >> 4;
+    const float sp = row == 0 ? q1p : row == 1 ? q2p : row == 2 ? p3 : 1.0f;
+    const float sh = row == 0 ? q1h : row == 1 ? q2h : row == 2 ? h3 : 0.0f;
+    H = fmaf(P, sh, H);
+    P = P * sp;
+}
+
+// wave64 sum with DPP adds; the total lands in lane 63 (read it with read_lane(v, 63)).
+__device__ __forceinline__ float wave_sum_dpp_to63(float v) {
+    v += dpp_mov<0x111>(0.0f, v);
+    v += dpp_mov<0x112>(0.0f, v);
+    v += dpp_mov<0x114>(0.0f, v);
+    v += dpp_mov<0x118>(0.0f, v);
+    v += dpp_mov<0x142, 0xa>(0.0f, v);
+    v += dpp_mov<0x143, 0xc>(0.0f, v);
+    return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);

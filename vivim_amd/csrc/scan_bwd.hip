@@ -14,6 +14,7 @@
 // second wave scan seeded by the carry of the step to the right (kept in per-wave LDS together with that
 // step's first decay factor), dB/dC are summed over the wave's R channels in registers before they leave
 // the wave.  No inter-wave communication, no barrier.
+#include <stdlib.h>
 #include "common.cuh"
 
 namespace vivim {
@@ -21,7 +22,7 @@ namespace vivim {
 constexpr int kBwdWaves = 4;
 
 template <typename T, int K, int R, bool HAS_Z, bool VAR_BC>
-__global__ void __launch_bounds__(kBwdWaves * kWave) ssm_bwd_kernel(const vivim_ssm_bwd_params p) {
+__global__ void __launch_bounds__(kBwdWaves * kWave) ssm_bwd_generic_kernel(const vivim_ssm_bwd_params p) {
     constexpr int TILE = kWave * K;
     const vivim_ssm_fwd_params& f = p.f;
     const int lane = threadIdx.x & 63;
@@ -242,6 +243,455 @@ __global__ void __launch_bounds__(kBwdWaves * kWave) ssm_bwd_kernel(const vivim_
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Fast path (variable B/C, dstate % 8 == 0 and <= 64, aligned rows, seqlen % K == 0).
+//   * workgroup = 8 waves = 16 channels of one batch element and one B/C group; a wave owns a channel
+//     PAIR and all N states; lane l holds K consecutive tokens of the 64*K-token step; steps are walked
+//     last -> first;
+//   * per state: forward re-scan of both channels (DPP scan, seeded by the forward kernel's checkpoint)
+//     and reverse scan of g (DPP in-row + read_lane row join), outputs accumulated in registers;
+//   * dB / dC: the pair's sum stays in registers; per state every wave drops its 2*K values per lane into
+//     its own LDS slot (plain stores -- ds_add_f32 measures 193 cycles per wave-instruction on gfx950,
+//     50x a ds_write), ONE barrier, then each thread sums the 8 slots of one (token, dB|dC) element in
+//     fixed order and issues one fp32 atomic to HBM: 1/16 of the per-channel atomics of the reference
+//     (bwd_kernel.cuh:312-313), which on MI355X would cap the kernel at the chip's ~1.3 TB/s atomic
+//     rate.  Slots are double-buffered on the state parity, so one barrier per state suffices;
+//   * every per-(channel, state) scalar the step needs (checkpoint, g carry, first decay of the step to the
+//     right, A, A*log2e, running dA) sits in a per-wave LDS record read with one ds_read_b128 pair.
+constexpr int kBwW = 8;            // waves per workgroup
+constexpr int kBwR = 2;            // channels per wave
+constexpr int kRec = 8;            // floats per (state, channel) record
+
+// Segment scratch (only when the token axis is split over S > 1 workgroups): the reverse recurrence needs,
+// at the right edge of every segment, g of the first token of the next one.
+struct BwdSeg {
+    int S, seg_steps;          // segments, steps per segment
+    float* agg;                // [batch][dim][S][dstate]  g at the segment's first token for zero inflow
+    float* dsum;               // [batch][dim][S]          sum over the segment of delta_{t+1}
+    float* gin;                // [batch][dim][S][dstate]  g flowing into the segment from the right
+};
+
+// MODE 0: the backward of one segment.  MODE 1: reverse aggregates of one segment only (pre-pass).
+template <typename T, int K, bool HAS_Z, int MINW, int MODE>
+__global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const vivim_ssm_bwd_params p, const BwdSeg sg) {
+    constexpr int R = kBwR;
+    constexpr int TILE = kWave * K;
+    static_assert(TILE == kChunk, "one checkpoint row per step");
+    static_assert(2 * TILE == kBwW * kWave, "one thread per (token, dB|dC) element of a step");
+    const vivim_ssm_fwd_params& f = p.f;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y;
+    const int N = f.dstate, L = f.seqlen;
+    const int cpg = f.dim / f.n_groups;
+    const int ppg = (cpg + R - 1) / R;                 // channel pairs per B/C group
+    const int bpg = (ppg + kBwW - 1) / kBwW;           // workgroups per group
+    const int g = blockIdx.x / bpg;
+    const int pair = (blockIdx.x - g * bpg) * kBwW + wave;
+    const bool active = pair < ppg;                    // surplus waves only help with barriers and the flush
+    const int d0 = g * cpg + min(pair, ppg - 1) * R;
+    const int nvalid = min(R, (g + 1) * cpg - d0);
+    const int nsteps = (L + TILE - 1) / TILE;
+    const int seg = MODE == 1 ? blockIdx.z + 1 : blockIdx.z;     // the pre-pass skips segment 0
+    const int s_lo = seg * sg.seg_steps, s_hi = min(nsteps, s_lo + sg.seg_steps);
+    const int t_next = s_hi * TILE;                   // first token right of the segment
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int SLOT = 2 * K * kWave;                // floats per wave slot: [dB k0..k3 | dC k0..k3][lane]
+    float* slots = smem;                               // [parity][wave][2K][64]
+    float* rec = smem + 2 * kBwW * SLOT + wave * (N * R * kRec);   // [n][r][kRec] wave-private records
+    enum { HCK = 0, GCAR = 1, AFIRST = 2, AVAL = 3, A2VAL = 4, DAACC = 5 };
+
+    int d[R];
+    float Dv[R], bias[R], msk[R], dD_acc[R], dbias_acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        d[r] = d0 + min(r, nvalid - 1);
+        Dv[r] = f.D ? static_cast<const float*>(f.D)[d[r]] : 0.0f;
+        bias[r] = f.delta_bias ? static_cast<const float*>(f.delta_bias)[d[r]] : 0.0f;
+        msk[r] = (active && r < nvalid) ? 1.0f : 0.0f;  // shadow slots / surplus waves contribute nothing
+        dD_acc[r] = 0.0f;
+        dbias_acc[r] = 0.0f;
+    }
+    const float* __restrict__ A = static_cast<const float*>(f.A);
+    float dl_nx[R];                                    // softplus(delta + bias) at the first token of the next segment
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        dl_nx[r] = 0.0f;
+        if (t_next < L) {
+            const float raw = to_f32<T>((static_cast<const T*>(f.delta) + b * f.delta_batch_stride + d[r] * f.delta_d_stride)[t_next]) + bias[r];
+            dl_nx[r] = f.delta_softplus ? softplus_ref(raw) : raw;
+        }
+    }
+    for (int i = lane; i < N * R; i += kWave) {
+        const int n = i / R, r = i - n * R;
+        const float a = A[d[r] * f.A_d_stride + n * f.A_dstate_stride];
+        float* q = rec + i * kRec;
+        q[GCAR] = (MODE == 0 && sg.S > 1) ? sg.gin[(((int64_t)b * f.dim + d[r]) * sg.S + seg) * N + n] : 0.0f;
+        q[AFIRST] = fast_exp2((r == 0 ? dl_nx[0] : dl_nx[1]) * a * kLog2e);   // exp2(0) = 1 past the end
+        q[AVAL] = a;
+        q[A2VAL] = a * kLog2e;
+        q[DAACC] = 0.0f;
+    }
+    wave_lds_fence();
+    // the (token, dB|dC) element this thread reduces after every state
+    const int e_tok = tid & (TILE - 1), e_isC = tid >> 8;          // 2*TILE == 512 threads
+    const int e_slot = (e_isC * K + (e_tok & (K - 1))) * kWave + (e_tok / K);
+
+    const T* __restrict__ uB = static_cast<const T*>(f.u) + b * f.u_batch_stride;
+    const T* __restrict__ dlB = static_cast<const T*>(f.delta) + b * f.delta_batch_stride;
+    const T* __restrict__ doB = static_cast<const T*>(p.dout) + b * p.dout_batch_stride;
+    const T* __restrict__ zB = HAS_Z ? static_cast<const T*>(f.z) + b * f.z_batch_stride : nullptr;
+    const T* __restrict__ oB = HAS_Z ? static_cast<const T*>(f.out) + b * f.out_batch_stride : nullptr;
+    const T* __restrict__ Bv = static_cast<const T*>(f.B) + b * f.B_batch_stride + g * f.B_group_stride;
+    const T* __restrict__ Cv = static_cast<const T*>(f.C) + b * f.C_batch_stride + g * f.C_group_stride;
+    float* __restrict__ dBg = static_cast<float*>(p.dB) + b * p.dB_batch_stride + g * p.dB_group_stride;
+    float* __restrict__ dCg = static_cast<float*>(p.dC) + b * p.dC_batch_stride + g * p.dC_group_stride;
+    const float* __restrict__ xck = static_cast<const float*>(f.x);
+
+    float dtot[R] = {0.0f, 0.0f}, dfirst[R] = {0.0f, 0.0f};
+    for (int step = s_hi - 1; step >= s_lo; --step) {
+        const int t0 = step * TILE + lane * K;
+        const bool in = t0 < L;                         // host guarantees L % K == 0: all-in or all-out
+        VIVIM_STAMP(nsteps - 1 - step, 0, wave, lane);
+        // forward checkpoints entering this step, one float per (state, channel)
+        if (MODE == 0)
+        for (int i = lane; i < N * R; i += kWave) {
+            const int n = i / R, r = i - n * R;
+            rec[i * kRec + HCK] = step > 0 ? xck[(((int64_t)b * f.dim + d[r]) * nsteps + (step - 1)) * N + n] : 0.0f;
+        }
+        float dl[R][K], w[R][K], uu[R][K], dy[R][K], S1[R][K], S2[R][K], dsum[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float df[K], dof[K];
+            unpack(load_vec<T, K>(uB + d[r] * f.u_d_stride + t0, in && MODE == 0), uu[r]);
+            unpack(load_vec<T, K>(dlB + d[r] * f.delta_d_stride + t0, in), df);
+            unpack(load_vec<T, K>(doB + d[r] * p.dout_d_stride + t0, in), dof);
+            if (HAS_Z) {
+                float zf[K], of[K], dzv[K];
+                unpack(load_vec<T, K>(zB + d[r] * f.z_d_stride + t0, in), zf);
+                unpack(load_vec<T, K>(oB + d[r] * f.out_d_stride + t0, in && MODE == 0), of);
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const float sg = sigmoidf_fast(zf[k]);
+                    dzv[k] = dof[k] * of[k] * sg * (1.0f + zf[k] * (1.0f - sg));     // bwd_kernel.cuh:186-191
+                    dof[k] *= zf[k] * sg;
+                }
+                // shadow slots write the same values to the same place as the slot they shadow: harmless
+                if (MODE == 0)
+                store_vec<T, K>(static_cast<T*>(p.dz) + b * p.dz_batch_stride + d[r] * p.dz_d_stride + t0, in && active, dzv);
+                if (MODE == 0 && f.out_z) {                                                        // bwd_kernel.cuh:193-204
+                    float oz[K];
+#pragma unroll
+                    for (int k = 0; k < K; ++k) oz[k] = of[k] * zf[k] * sigmoidf_fast(zf[k]);
+                    store_vec<T, K>(static_cast<T*>(f.out_z) + b * f.out_z_batch_stride + d[r] * f.out_z_d_stride + t0, in && active, oz);
+                }
+            }
+            dsum[r] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float raw = df[k] + bias[r];
+                const float sp = f.delta_softplus ? softplus_ref(raw) : raw;
+                dl[r][k] = in ? sp : 0.0f;              // padded tokens: identity maps both ways
+                dsum[r] += dl[r][k];
+                w[r][k] = dl[r][k] * uu[r][k];
+                dy[r][k] = dof[k];
+                S1[r][k] = 0.0f;
+                S2[r][k] = 0.0f;
+                dD_acc[r] = fmaf(dof[k], uu[r][k], dD_acc[r]);
+            }
+            if (MODE == 1) {
+                dtot[r] += dsum[r];
+                dfirst[r] = read_lane(dl[r][0], 0);
+            }
+        }
+        wave_lds_fence();
+        VIVIM_STAMP(nsteps - 1 - step, 1, wave, lane);
+        {
+            RawK<T, K> Braw = load_vec<T, K>(Bv + t0, in);
+            RawK<T, K> Craw = load_vec<T, K>(Cv + t0, in);
+#pragma unroll 1
+            for (int n = 0; n < N; ++n) {
+                float Bn[K], Cn[K];
+                unpack(Braw, Bn);
+                unpack(Craw, Cn);
+                {
+                    const bool nx = in && (n + 1 < N);
+                    Braw = load_vec<T, K>(Bv + (n + 1) * f.B_dstate_stride + t0, nx);   // flies during this state
+                    Craw = load_vec<T, K>(Cv + (n + 1) * f.C_dstate_stride + t0, nx);
+                }
+                if (n == 1) VIVIM_STAMP(nsteps - 1 - step, 11, wave, lane);
+                float q[R][kRec];
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int j = 0; j < kRec; ++j) q[r][j] = rec[(n * R + r) * kRec + j];
+                if (n == 1) VIVIM_STAMP(nsteps - 1 - step, 12, wave, lane);
+                // ---- forward re-scan ----
+                float a[R][K], hs[R][K], P[R], H[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    P[r] = fast_exp2(dsum[r] * q[r][A2VAL]);
+                    H[r] = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        a[r][k] = fast_exp2(dl[r][k] * q[r][A2VAL]);
+                        H[r] = fmaf(a[r][k], H[r], w[r][k] * Bn[k]);
+                        hs[r][k] = 0.0f;
+                    }
+                }
+                if (MODE == 0) {
+                    wave_scan2_affine_fwd(P[0], H[0], P[1], H[1]);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const float hend = fmaf(P[r], q[r][HCK], H[r]);
+                        float h = dpp_mov<kDppWaveShr1>(q[r][HCK], hend);    // state entering this lane
+#pragma unroll
+                        for (int k = 0; k < K; ++k) {
+                            h = fmaf(a[r][k], h, w[r][k] * Bn[k]);
+                            hs[r][k] = h;
+                        }
+                    }
+                }
+                if (n == 1) VIVIM_STAMP(nsteps - 1 - step, 13, wave, lane);
+                // ---- reverse scan of g_t = a_{t+1} g_{t+1} + C_t dy_t ----
+                float an[R], Pr[R], G[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    an[r] = dpp_mov<kDppWaveShl1>(q[r][AFIRST], a[r][0]);    // decay of the token right of this lane
+                    Pr[r] = an[r];
+                    G[r] = 0.0f;
+#pragma unroll
+                    for (int k = K - 1; k >= 0; --k) {
+                        const float al = k == K - 1 ? an[r] : a[r][k + 1];
+                        G[r] = fmaf(al, G[r], Cn[k] * dy[r][k]);
+                        if (k < K - 1) Pr[r] *= al;
+                    }
+                }
+                wave_scan2_affine_rev_rows(Pr[0], G[0], Pr[1], G[1]);
+                float dBv[K], dCv[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) { dBv[k] = 0.0f; dCv[k] = 0.0f; }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    wave_scan_rev_join(Pr[r], G[r], lane);
+                    const float gfirst = fmaf(Pr[r], q[r][GCAR], G[r]);      // g at this lane's first token
+                    float gc = dpp_mov<kDppWaveShl1>(q[r][GCAR], gfirst);    // g at the token right of this lane
+                    float dA_part = 0.0f;
+                    if (MODE == 0)
+#pragma unroll
+                    for (int k = K - 1; k >= 0; --k) {
+                        const float al = k == K - 1 ? an[r] : a[r][k + 1];
+                        gc = fmaf(al, gc, Cn[k] * dy[r][k]);                 // g_t
+                        const float ahp = hs[r][k] - w[r][k] * Bn[k];        // a_t h_{t-1}
+                        const float t = gc * ahp;
+                        S1[r][k] = fmaf(gc, Bn[k], S1[r][k]);                // du = D dy + d * S1
+                        S2[r][k] = fmaf(t, q[r][AVAL], S2[r][k]);            // dd = u * S1 + S2
+                        dA_part = fmaf(t, dl[r][k], dA_part);
+                        dBv[k] = fmaf(gc * msk[r], w[r][k], dBv[k]);
+                        dCv[k] = fmaf(dy[r][k] * msk[r], hs[r][k], dCv[k]);
+                    }
+                    const float dA_tot = MODE == 0 ? read_lane(wave_sum_dpp_to63(dA_part), 63) : 0.0f;
+                    const float g0 = read_lane(gfirst, 0), a0 = read_lane(a[r][0], 0);
+                    if (lane == 0) {
+                        float* qq = rec + (n * R + r) * kRec;
+                        qq[GCAR] = g0;                                       // g at this step's first token
+                        qq[AFIRST] = a0;
+                        qq[DAACC] = q[r][DAACC] + dA_tot;
+                    }
+                }
+                if (n == 1) VIVIM_STAMP(nsteps - 1 - step, 14, wave, lane);
+                if (MODE == 1) { wave_lds_fence(); continue; }
+                {
+                    float* sl = slots + ((n & 1) * kBwW + wave) * SLOT + lane;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        sl[k * kWave] = dBv[k];
+                        sl[(K + k) * kWave] = dCv[k];
+                    }
+                }
+                lds_barrier();
+                {   // fixed-order sum over the workgroup's 8 channel pairs, then one fp32 atomic per element
+                    const float* sp = slots + (n & 1) * kBwW * SLOT + e_slot;
+                    float acc = sp[0];
+#pragma unroll
+                    for (int wv = 1; wv < kBwW; ++wv) acc += sp[wv * SLOT];
+                    const int t = step * TILE + e_tok;
+                    if (t < L)                                             // fp32 sum over workgroups (bwd_kernel.cuh:312-313)
+                        atomicAdd((e_isC ? dCg + n * p.dC_dstate_stride : dBg + n * p.dB_dstate_stride) + t, acc);
+                }
+                if (n == 1) VIVIM_STAMP(nsteps - 1 - step, 15, wave, lane);
+                if (n < 4) VIVIM_STAMP(nsteps - 1 - step, 2 + n, wave, lane);
+            }
+            VIVIM_STAMP(nsteps - 1 - step, 6, wave, lane);
+            VIVIM_STAMP(nsteps - 1 - step, 7, wave, lane);
+            VIVIM_STAMP(nsteps - 1 - step, 8, wave, lane);
+            VIVIM_STAMP(nsteps - 1 - step, 9, wave, lane);
+        }
+        // ---- per-channel outputs of the step ----
+        if (MODE == 0)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float duv[K], ddv[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                duv[k] = fmaf(dl[r][k], S1[r][k], Dv[r] * dy[r][k]);
+                ddv[k] = fmaf(uu[r][k], S1[r][k], S2[r][k]);
+            }
+            if (f.delta_softplus) {                                           // bwd_kernel.cuh:439-452
+                // sigmoid(raw) = 1 - exp(-softplus(raw)); exact for raw > 20 too (softplus = raw there, and
+                // the reference leaves ddelta unscaled: 1 - exp(-20) rounds to 1 in fp32)
+                float df[K];
+                unpack(load_vec<T, K>(dlB + d[r] * f.delta_d_stride + t0, in), df);
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const float raw = df[k] + bias[r];
+                    if (raw <= 20.0f) ddv[k] *= sigmoidf_fast(raw);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) dbias_acc[r] += in ? ddv[k] : 0.0f;
+            store_vec<T, K>(static_cast<T*>(p.du) + b * p.du_batch_stride + d[r] * p.du_d_stride + t0, in && active, duv);
+            store_vec<T, K>(static_cast<T*>(p.ddelta) + b * p.ddelta_batch_stride + d[r] * p.ddelta_d_stride + t0, in && active, ddv);
+        }
+        VIVIM_STAMP(nsteps - 1 - step, 10, wave, lane);
+    }
+    if (MODE == 1) {
+        wave_lds_fence();
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float tot = wave_sum(dtot[r]);                         // sum_{t in seg} delta_t
+                if (lane == 0 && r < nvalid)
+                    sg.dsum[((int64_t)b * f.dim + d[r]) * sg.S + seg] = tot - dfirst[r] + dl_nx[r];
+            }
+            for (int i = lane; i < N * R; i += kWave) {
+                const int n = i / R, r = i - n * R;
+                if (r < nvalid)
+                    sg.agg[(((int64_t)b * f.dim + d0 + r) * sg.S + seg) * N + n] = rec[i * kRec + GCAR];
+            }
+        }
+        return;
+    }
+    if (active) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (r >= nvalid) break;
+            const float sD = wave_sum(dD_acc[r]);
+            const float sb = wave_sum(dbias_acc[r]);
+            if (lane == 0) {
+                if (p.dD) atomicAdd(static_cast<float*>(p.dD) + d[r], sD);
+                if (p.ddelta_bias) atomicAdd(static_cast<float*>(p.ddelta_bias) + d[r], sb);
+            }
+        }
+        wave_lds_fence();
+        for (int i = lane; i < N * R; i += kWave) {
+            const int n = i / R, r = i - n * R;
+            if (r < nvalid)
+                atomicAdd(static_cast<float*>(p.dA) + (d0 + r) * p.dA_d_stride + n * p.dA_dstate_stride,
+                          rec[i * kRec + DAACC]);
+        }
+    }
+}
+
+// gin[seg-1] = exp2(A2 * dsum[seg]) * gin[seg] + agg[seg], right to left; one thread per (batch, channel, state)
+__global__ void ssm_bwd_carry_kernel(const vivim_ssm_bwd_params p, const BwdSeg sg) {
+    const vivim_ssm_fwd_params& f = p.f;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = f.dstate;
+    if (i >= (int64_t)f.batch * f.dim * N) return;
+    const int n = (int)(i % N);
+    const int64_t bd = i / N;
+    const int dch = (int)(bd % f.dim);
+    const float A2 = static_cast<const float*>(f.A)[dch * f.A_d_stride + n * f.A_dstate_stride] * kLog2e;
+    float g = 0.0f;
+    sg.gin[(bd * sg.S + sg.S - 1) * N + n] = 0.0f;
+    for (int s = sg.S - 1; s >= 1; --s) {
+        g = fmaf(fast_exp2(A2 * sg.dsum[bd * sg.S + s]), g, sg.agg[(bd * sg.S + s) * N + n]);
+        sg.gin[(bd * sg.S + s - 1) * N + n] = g;
+    }
+}
+
+// How the token axis is cut: enough workgroups to give every CU ~4, segments of whole 256-token steps.
+static void bwd_segmentation(const vivim_ssm_fwd_params& f, int& S, int& seg_steps) {
+    const int nsteps = (f.seqlen + kChunk - 1) / kChunk;
+    const int cpg = f.dim / f.n_groups;
+    const int ppg = (cpg + kBwR - 1) / kBwR;
+    const int64_t wgs = (int64_t)((ppg + kBwW - 1) / kBwW) * f.n_groups * f.batch;
+    int want = (int)((1024 + wgs - 1) / wgs);
+    if (want > 64) want = 64;
+    if (want > nsteps) want = nsteps;
+    if (want < 1) want = 1;
+    seg_steps = (nsteps + want - 1) / want;
+    S = (nsteps + seg_steps - 1) / seg_steps;
+}
+
+size_t scan_bwd_workspace_bytes(const vivim_ssm_fwd_params& f) {
+    if (!f.is_variable_B || !f.is_variable_C || f.dstate > 64) return 0;
+    int S, seg_steps;
+    bwd_segmentation(f, S, seg_steps);
+    if (S <= 1) return 0;
+    return ((size_t)f.batch * f.dim * S * (2 * f.dstate + 1)) * sizeof(float);
+}
+
+template <typename T, int K, int MINW>
+static void launch_bwd_fast(const vivim_ssm_bwd_params& p, hipStream_t stream) {
+    const vivim_ssm_fwd_params& f = p.f;
+    const int cpg = f.dim / f.n_groups;
+    const int ppg = (cpg + kBwR - 1) / kBwR;
+    const int bpg = (ppg + kBwW - 1) / kBwW;
+    BwdSeg sg = {1, (f.seqlen + kChunk - 1) / kChunk, nullptr, nullptr, nullptr};
+    const size_t need = scan_bwd_workspace_bytes(f);
+    if (need && p.workspace && (size_t)p.workspace_bytes >= need) {
+        bwd_segmentation(f, sg.S, sg.seg_steps);
+        const size_t nbd = (size_t)f.batch * f.dim * sg.S;
+        sg.agg = static_cast<float*>(p.workspace);
+        sg.gin = sg.agg + nbd * f.dstate;
+        sg.dsum = sg.gin + nbd * f.dstate;
+    }
+    const dim3 block(kBwW * kWave);
+    const size_t smem = ((size_t)2 * kBwW * 2 * K * kWave + (size_t)kBwW * f.dstate * kBwR * kRec) * sizeof(float);
+    if (sg.S > 1) {
+        dim3 gpre(bpg * f.n_groups, f.batch, sg.S - 1);
+        if (f.z) hipLaunchKernelGGL((ssm_bwd_fast_kernel<T, K, true, MINW, 1>), gpre, block, smem, stream, p, sg);
+        else     hipLaunchKernelGGL((ssm_bwd_fast_kernel<T, K, false, MINW, 1>), gpre, block, smem, stream, p, sg);
+        const int64_t nthr = (int64_t)f.batch * f.dim * f.dstate;
+        hipLaunchKernelGGL(ssm_bwd_carry_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream, p, sg);
+    }
+    dim3 grid(bpg * f.n_groups, f.batch, sg.S);
+    if (f.z) hipLaunchKernelGGL((ssm_bwd_fast_kernel<T, K, true, MINW, 0>), grid, block, smem, stream, p, sg);
+    else     hipLaunchKernelGGL((ssm_bwd_fast_kernel<T, K, false, MINW, 0>), grid, block, smem, stream, p, sg);
+}
+
+template <typename T>
+static bool try_bwd_fast(const vivim_ssm_bwd_params& p, hipStream_t stream) {
+    const vivim_ssm_fwd_params& f = p.f;
+    constexpr int K = 4;
+    if (!f.is_variable_B || !f.is_variable_C || f.dstate > 64 || f.x == nullptr) return false;
+    static const int forced = [] { const char* e = getenv("VIVIM_BWD_VARIANT"); return e ? atoi(e) : 0; }();
+    if (forced == 3) return false;
+    // unconditional K-element vectors: rows aligned to the vector size, seqlen a whole number of lanes
+    const int64_t vb = K * (int64_t)sizeof(T) >= 16 ? 16 : K * (int64_t)sizeof(T);
+    const int64_t epv = vb / (int64_t)sizeof(T);
+    auto al = [&](const void* q) { return (reinterpret_cast<uintptr_t>(q) & (vb - 1)) == 0; };
+    auto st = [&](int64_t e) { return e % epv == 0; };
+    if (f.seqlen % K != 0 || !al(f.u) || !al(f.delta) || !al(f.B) || !al(f.C) || !al(p.dout) || !al(p.du) || !al(p.ddelta) ||
+        !st(f.u_batch_stride) || !st(f.u_d_stride) || !st(f.delta_batch_stride) || !st(f.delta_d_stride) ||
+        !st(p.dout_batch_stride) || !st(p.dout_d_stride) || !st(p.du_batch_stride) || !st(p.du_d_stride) ||
+        !st(p.ddelta_batch_stride) || !st(p.ddelta_d_stride) || !st(f.B_batch_stride) || !st(f.B_group_stride) ||
+        !st(f.B_dstate_stride) || !st(f.C_batch_stride) || !st(f.C_group_stride) || !st(f.C_dstate_stride))
+        return false;
+    if (f.z && (!al(f.z) || !al(f.out) || !al(p.dz) || !st(f.z_batch_stride) || !st(f.z_d_stride) ||
+                !st(f.out_batch_stride) || !st(f.out_d_stride) || !st(p.dz_batch_stride) || !st(p.dz_d_stride) ||
+                (f.out_z && (!al(f.out_z) || !st(f.out_z_batch_stride) || !st(f.out_z_d_stride)))))
+        return false;
+    if (forced == 1) launch_bwd_fast<T, K, 4>(p, stream);
+    else             launch_bwd_fast<T, K, 2>(p, stream);
+    return true;
+}
+
 template <typename T, int K, int R>
 static void launch_bwd(const vivim_ssm_bwd_params& p, hipStream_t stream) {
     const vivim_ssm_fwd_params& f = p.f;
@@ -251,19 +701,19 @@ static void launch_bwd(const vivim_ssm_bwd_params& p, hipStream_t stream) {
     const size_t smem = (size_t)kBwdWaves * 3 * R * f.dstate * sizeof(float);
     const bool var = f.is_variable_B;
     if (f.z) {
-        if (var) hipLaunchKernelGGL((ssm_bwd_kernel<T, K, R, true, true>), grid, dim3(kBwdWaves * kWave), smem, stream, p);
-        else     hipLaunchKernelGGL((ssm_bwd_kernel<T, K, R, true, false>), grid, dim3(kBwdWaves * kWave), smem, stream, p);
+        if (var) hipLaunchKernelGGL((ssm_bwd_generic_kernel<T, K, R, true, true>), grid, dim3(kBwdWaves * kWave), smem, stream, p);
+        else     hipLaunchKernelGGL((ssm_bwd_generic_kernel<T, K, R, true, false>), grid, dim3(kBwdWaves * kWave), smem, stream, p);
     } else {
-        if (var) hipLaunchKernelGGL((ssm_bwd_kernel<T, K, R, false, true>), grid, dim3(kBwdWaves * kWave), smem, stream, p);
-        else     hipLaunchKernelGGL((ssm_bwd_kernel<T, K, R, false, false>), grid, dim3(kBwdWaves * kWave), smem, stream, p);
+        if (var) hipLaunchKernelGGL((ssm_bwd_generic_kernel<T, K, R, false, true>), grid, dim3(kBwdWaves * kWave), smem, stream, p);
+        else     hipLaunchKernelGGL((ssm_bwd_generic_kernel<T, K, R, false, false>), grid, dim3(kBwdWaves * kWave), smem, stream, p);
     }
 }
 
 bool ssm_bwd_dispatch(const vivim_ssm_bwd_params& p, hipStream_t s) {
     switch (p.f.itype) {
-        case VIVIM_F32: launch_bwd<float, 4, 2>(p, s); return true;
-        case VIVIM_F16: launch_bwd<f16_t, 4, 2>(p, s); return true;
-        case VIVIM_BF16: launch_bwd<bf16_t, 4, 2>(p, s); return true;
+        case VIVIM_F32: if (!try_bwd_fast<float>(p, s)) launch_bwd<float, 4, 2>(p, s); return true;
+        case VIVIM_F16: if (!try_bwd_fast<f16_t>(p, s)) launch_bwd<f16_t, 4, 2>(p, s); return true;
+        case VIVIM_BF16: if (!try_bwd_fast<bf16_t>(p, s)) launch_bwd<bf16_t, 4, 2>(p, s); return true;
     }
     return false;
 }

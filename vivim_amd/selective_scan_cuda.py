@@ -171,6 +171,10 @@ def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softp
         P.dB_batch_stride, P.dB_group_stride, P.dB_dstate_stride = 0, dB.stride(0), dB.stride(1)
         P.dC_batch_stride, P.dC_group_stride, P.dC_dstate_stride = 0, dC.stride(0), dC.stride(1)
     P.dD, P.ddelta_bias = _ptr(dD), _ptr(ddelta_bias)
+    ws_bytes = _lib.lib().vivim_scan_bwd_workspace_bytes(P.f)
+    if ws_bytes:
+        workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=u.device)   # torch caching allocator: no sync
+        P.workspace, P.workspace_bytes = workspace.data_ptr(), ws_bytes
     with torch.cuda.device(u.device):
         _lib.call("vivim_selective_scan_bwd", P, torch.cuda.current_stream().cuda_stream)
     result = [du, ddelta, dA, dB.to(B.dtype), dC.to(C.dtype), dD, ddelta_bias]
