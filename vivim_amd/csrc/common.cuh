@@ -135,6 +135,24 @@ __device__ __forceinline__ RawK<T, K> load_vec(const T* __restrict__ p, bool pre
     }
     return u.r;
 }
+// Same, but the load is ALWAYS issued (from `safe` when !pred) so that the compiler can count it in
+// s_waitcnt vmcnt(N): a load under a divergent branch makes every later wait a full vmcnt(0) drain.
+template <typename T, int K>
+__device__ __forceinline__ RawK<T, K> load_vec_always(const T* __restrict__ p, bool pred, const T* __restrict__ safe) {
+    constexpr int BYTES = K * (int)sizeof(T);
+    constexpr int VB = BYTES >= 16 ? 16 : BYTES;
+    constexpr int NV = BYTES / VB;
+    using V = typename Pack<T, VB>::type;
+    union { V raw[NV]; RawK<T, K> r; } u;
+    const V* q = reinterpret_cast<const V*>(pred ? p : safe);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const V v = q[i];
+        u.raw[i] = pred ? v : V(0);
+    }
+    return u.r;
+}
+
 template <typename T, int K>
 __device__ __forceinline__ void store_vec(T* __restrict__ p, bool pred, const float (&v)[K]) {
     constexpr int BYTES = K * (int)sizeof(T);

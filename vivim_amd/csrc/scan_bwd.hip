@@ -410,17 +410,17 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
         wave_lds_fence();
         VIVIM_STAMP(nsteps - 1 - step, 1, wave, lane);
         {
-            RawK<T, K> Braw = load_vec<T, K>(Bv + t0, in);
-            RawK<T, K> Craw = load_vec<T, K>(Cv + t0, in);
+            RawK<T, K> Braw = load_vec_always<T, K>(Bv + t0, in, Bv);
+            RawK<T, K> Craw = load_vec_always<T, K>(Cv + t0, in, Cv);
 #pragma unroll 1
             for (int n = 0; n < N; ++n) {
                 float Bn[K], Cn[K];
                 unpack(Braw, Bn);
                 unpack(Craw, Cn);
-                {
+                {   // next state's rows fly during this state (always issued, so vmcnt stays countable)
                     const bool nx = in && (n + 1 < N);
-                    Braw = load_vec<T, K>(Bv + (n + 1) * f.B_dstate_stride + t0, nx);   // flies during this state
-                    Craw = load_vec<T, K>(Cv + (n + 1) * f.C_dstate_stride + t0, nx);
+                    Braw = load_vec_always<T, K>(Bv + (n + 1) * f.B_dstate_stride + t0, nx, Bv);
+                    Craw = load_vec_always<T, K>(Cv + (n + 1) * f.C_dstate_stride + t0, nx, Cv);
                 }
                 if (n == 1) VIVIM_STAMP(nsteps - 1 - step, 11, wave, lane);
                 float q[R][kRec];
@@ -518,9 +518,11 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
                     float acc = sp[0];
 #pragma unroll
                     for (int wv = 1; wv < kBwW; ++wv) acc += sp[wv * SLOT];
-                    const int t = step * TILE + e_tok;
-                    if (t < L)                                             // fp32 sum over workgroups (bwd_kernel.cuh:312-313)
-                        atomicAdd((e_isC ? dCg + n * p.dC_dstate_stride : dBg + n * p.dB_dstate_stride) + t, acc);
+                    // fp32 sum over workgroups (bwd_kernel.cuh:312-313).  Unconditional: elements past the end
+                    // carry acc == 0 (their dy and delta*u are 0) and are wrapped onto distinct valid tokens.
+                    const int tq = step * TILE + e_tok;
+                    const int t = tq < L ? tq : tq % L;
+                    atomicAdd((e_isC ? dCg + n * p.dC_dstate_stride : dBg + n * p.dB_dstate_stride) + t, acc);
                 }
                 if (n == 1) VIVIM_STAMP(nsteps - 1 - step, 15, wave, lane);
                 if (n < 4) VIVIM_STAMP(nsteps - 1 - step, 2 + n, wave, lane);
@@ -687,8 +689,8 @@ static bool try_bwd_fast(const vivim_ssm_bwd_params& p, hipStream_t stream) {
                 !st(f.out_batch_stride) || !st(f.out_d_stride) || !st(p.dz_batch_stride) || !st(p.dz_d_stride) ||
                 (f.out_z && (!al(f.out_z) || !st(f.out_z_batch_stride) || !st(f.out_z_d_stride)))))
         return false;
-    if (forced == 1) launch_bwd_fast<T, K, 4>(p, stream);
-    else             launch_bwd_fast<T, K, 2>(p, stream);
+    if (forced == 2) launch_bwd_fast<T, K, 2>(p, stream);   // uncapped registers (tuning only)
+    else             launch_bwd_fast<T, K, 4>(p, stream);   // <= 128 VGPRs: two workgroups per CU
     return true;
 }
 

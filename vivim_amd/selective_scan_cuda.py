@@ -140,11 +140,15 @@ def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softp
             out_z = torch.empty_like(out_)
     du = torch.empty_like(u)
     ddelta = torch.empty_like(delta)
-    dA = torch.zeros_like(A)
-    dB = torch.zeros_like(B, dtype=torch.float32)      # fp32 accumulators, cast on return (selective_scan.cpp:460-461)
-    dC = torch.zeros_like(C, dtype=torch.float32)
-    dD = torch.zeros_like(D_) if D_ is not None else None
-    ddelta_bias = torch.zeros_like(delta_bias_) if delta_bias_ is not None else None
+    # fp32 accumulators (selective_scan.cpp:458-466) carved out of ONE zero-filled buffer: one memset
+    # instead of five, and dB|dC are adjacent so their cast to the input dtype is one kernel too.
+    nB, nC, nA = B.numel(), C.numel(), A.numel()
+    acc = torch.zeros(nB + nC + nA + 2 * dim, device=u.device, dtype=torch.float32)
+    dB = acc[:nB].view(B.shape)
+    dC = acc[nB:nB + nC].view(C.shape)
+    dA = acc[nB + nC:nB + nC + nA].view(A.shape)
+    dD = acc[nB + nC + nA:nB + nC + nA + dim] if D_ is not None else None
+    ddelta_bias = acc[nB + nC + nA + dim:] if delta_bias_ is not None else None
 
     P = _lib.SsmBwdParams()
     _fill_fwd(P.f, u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, dims)
@@ -177,7 +181,12 @@ def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softp
         P.workspace, P.workspace_bytes = workspace.data_ptr(), ws_bytes
     with torch.cuda.device(u.device):
         _lib.call("vivim_selective_scan_bwd", P, torch.cuda.current_stream().cuda_stream)
-    result = [du, ddelta, dA, dB.to(B.dtype), dC.to(C.dtype), dD, ddelta_bias]
+    if var_B and var_C and B.dtype != torch.float32:
+        dBC = acc[:nB + nC].to(B.dtype)
+        dB_out, dC_out = dBC[:nB].view(B.shape), dBC[nB:].view(C.shape)
+    else:
+        dB_out, dC_out = dB.to(B.dtype), dC.to(C.dtype)
+    result = [du, ddelta, dA, dB_out, dC_out, dD, ddelta_bias]
     if has_z:
         result.append(dz)
     if recompute_out_z:
