@@ -133,11 +133,40 @@ typedef struct {
     void *dbias;                /* (dim) f32 pre-zeroed, or NULL iff bias == NULL */
 } vivim_conv_bwd_params;
 
+/* ---- depthwise 3x3 / 3x3x3 convolution on token-major tensors ---------------
+ * Replaces the ATen call behind modeling/vivim.py:57-68 (DWConv: nn.Conv3d(dim, dim, 3, 1, 1, groups=dim) applied
+ * to x.transpose(1, 2).view(B, C, nf, H, W)); the reference has no kernel of its own there.
+ * x, y: (batch, depth*height*width, channels), channels contiguous, token stride and batch stride free.
+ * wt: (kd*9, channels) f32, TAP-major: wt[(kd*3 + kh)*3 + kw][c] = conv.weight[c][0][kd][kh][kw].
+ * flip = 1 correlates with the reversed tap order: the input gradient of the same convolution. */
+typedef struct {
+    int32_t batch, depth, height, width, channels;
+    int32_t kd;                 /* 1 (2-D, 3x3) or 3 (3-D, 3x3x3) */
+    int32_t itype;              /* dtype of x and y; channels % (16 / sizeof) == 0 and 16-byte aligned rows */
+    int32_t flip;
+    int64_t x_batch_stride, x_token_stride;
+    int64_t y_batch_stride, y_token_stride;
+    const void *x, *wt, *bias;  /* bias (channels) f32 or NULL */
+    void *y;
+} vivim_dwconv_params;
+
+typedef struct {
+    int32_t batch, depth, height, width, channels;
+    int32_t kd;
+    int32_t itype;              /* dtype of x and dy; channels % 2 == 0 */
+    int32_t _pad0;
+    int64_t x_batch_stride, x_token_stride;
+    int64_t dy_batch_stride, dy_token_stride;
+    const void *x, *dy;
+    void *dwt;                  /* (kd*9, channels) f32 tap-major, pre-zeroed */
+    void *dbias;                /* (channels) f32 pre-zeroed, or NULL */
+} vivim_dwconv_wgrad_params;
+
 int vivim_abi_version(void);
 const char *vivim_last_error(void);
 
 /* sizeof() of a params struct as this library was compiled, so a foreign-language binding can assert
- * its own layout: which = 0 ssm_fwd, 1 ssm_bwd, 2 conv_fwd, 3 conv_bwd; 0 for anything else. */
+ * its own layout: which = 0 ssm_fwd, 1 ssm_bwd, 2 conv_fwd, 3 conv_bwd, 4 dwconv, 5 dwconv_wgrad; 0 for anything else. */
 size_t vivim_sizeof(int which);
 
 /* Tokens per checkpoint row of `x` for an input dtype; n_chunks = ceil(seqlen / chunk_len). */
@@ -151,6 +180,8 @@ int vivim_selective_scan_fwd(const vivim_ssm_fwd_params *p, void *stream);
 int vivim_selective_scan_bwd(const vivim_ssm_bwd_params *p, void *stream);
 int vivim_causal_conv1d_fwd(const vivim_conv_fwd_params *p, void *stream);
 int vivim_causal_conv1d_bwd(const vivim_conv_bwd_params *p, void *stream);
+int vivim_dwconv_fwd(const vivim_dwconv_params *p, void *stream);            /* also the input gradient (flip = 1) */
+int vivim_dwconv_wgrad(const vivim_dwconv_wgrad_params *p, void *stream);
 
 #ifdef __cplusplus
 }

@@ -26,7 +26,8 @@ def test_header_symbols_exported():
 
 def test_struct_layouts_match():
     L = _lib.lib()
-    for which, st in enumerate((_lib.SsmFwdParams, _lib.SsmBwdParams, _lib.ConvFwdParams, _lib.ConvBwdParams)):
+    for which, st in enumerate((_lib.SsmFwdParams, _lib.SsmBwdParams, _lib.ConvFwdParams, _lib.ConvBwdParams,
+                                _lib.DwConvParams, _lib.DwConvWgradParams)):
         assert L.vivim_sizeof(which) == ctypes.sizeof(st)
     assert L.vivim_sizeof(99) == 0
     assert L.vivim_abi_version() == 2

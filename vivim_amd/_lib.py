@@ -62,10 +62,26 @@ class ConvBwdParams(ctypes.Structure):
     )
 
 
+class DwConvParams(ctypes.Structure):
+    _fields_ = (
+        [(n, i32) for n in ("batch", "depth", "height", "width", "channels", "kd", "itype", "flip")]
+        + [(n, i64) for n in ("x_batch_stride", "x_token_stride", "y_batch_stride", "y_token_stride")]
+        + [(n, vp) for n in ("x", "wt", "bias", "y")]
+    )
+
+
+class DwConvWgradParams(ctypes.Structure):
+    _fields_ = (
+        [(n, i32) for n in ("batch", "depth", "height", "width", "channels", "kd", "itype", "_pad0")]
+        + [(n, i64) for n in ("x_batch_stride", "x_token_stride", "dy_batch_stride", "dy_token_stride")]
+        + [(n, vp) for n in ("x", "dy", "dwt", "dbias")]
+    )
+
+
 EXPORTS = ("vivim_abi_version", "vivim_last_error", "vivim_scan_chunk_len", "vivim_sizeof",
            "vivim_scan_bwd_workspace_bytes",
            "vivim_selective_scan_fwd", "vivim_selective_scan_bwd",
-           "vivim_causal_conv1d_fwd", "vivim_causal_conv1d_bwd")
+           "vivim_causal_conv1d_fwd", "vivim_causal_conv1d_bwd", "vivim_dwconv_fwd", "vivim_dwconv_wgrad")
 
 _lib = None
 
@@ -93,13 +109,15 @@ def lib():
         L.vivim_scan_bwd_workspace_bytes.restype = ctypes.c_size_t
         L.vivim_scan_bwd_workspace_bytes.argtypes = [ctypes.POINTER(SsmFwdParams)]
         for name, st in (("vivim_selective_scan_fwd", SsmFwdParams), ("vivim_selective_scan_bwd", SsmBwdParams),
-                         ("vivim_causal_conv1d_fwd", ConvFwdParams), ("vivim_causal_conv1d_bwd", ConvBwdParams)):
+                         ("vivim_causal_conv1d_fwd", ConvFwdParams), ("vivim_causal_conv1d_bwd", ConvBwdParams),
+                         ("vivim_dwconv_fwd", DwConvParams), ("vivim_dwconv_wgrad", DwConvWgradParams)):
             fn = getattr(L, name)
             fn.argtypes = [ctypes.POINTER(st), vp]
             fn.restype = ctypes.c_int
         if L.vivim_abi_version() != 2:
             raise ImportError("libvivim_hip.so ABI version mismatch")
-        for which, st in enumerate((SsmFwdParams, SsmBwdParams, ConvFwdParams, ConvBwdParams)):
+        for which, st in enumerate((SsmFwdParams, SsmBwdParams, ConvFwdParams, ConvBwdParams, DwConvParams,
+                                    DwConvWgradParams)):
             if L.vivim_sizeof(which) != ctypes.sizeof(st):
                 raise ImportError(f"struct layout mismatch for {st.__name__}: "
                                   f"C {L.vivim_sizeof(which)} vs ctypes {ctypes.sizeof(st)}")
@@ -125,6 +143,9 @@ def algorithmic_bytes(name, P):
         n_act = 5 + (3 if has_z else 0) + (1 if (has_z and f.out_z) else 0)   # u, delta, dout, du, ddelta (+ z, out, dz) (+ out_z)
         return (n_act * act + 2 * bc * (s if f.is_variable_B else 4) + 2 * bc * 4
                 + 4 * (2 * f.dim * f.dstate + 4 * f.dim))
+    if name.startswith("vivim_dwconv"):
+        act = P.batch * P.depth * P.height * P.width * P.channels * _ISIZE[P.itype]
+        return 2 * act + 4 * P.channels * (P.kd * 9 + 1)            # x and y (or x and dy) once + taps
     f = P.f if name.endswith("bwd") else P
     s = _ISIZE[f.itype]
     act = f.batch * f.dim * f.seqlen * s

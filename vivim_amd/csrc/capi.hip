@@ -10,6 +10,8 @@ namespace vivim {
 bool conv_fwd_dispatch(const vivim_conv_fwd_params&, hipStream_t);
 bool conv_bwd_dispatch(const vivim_conv_bwd_params&, hipStream_t);
 bool ssm_fwd_dispatch(const vivim_ssm_fwd_params&, hipStream_t);
+bool dwconv_fwd_dispatch(const vivim_dwconv_params&, hipStream_t);
+bool dwconv_wgrad_dispatch(const vivim_dwconv_wgrad_params&, hipStream_t);
 bool ssm_bwd_dispatch(const vivim_ssm_bwd_params&, hipStream_t);
 int scan_chunk_len(int itype);
 size_t scan_bwd_workspace_bytes(const vivim_ssm_fwd_params&);
@@ -72,6 +74,8 @@ size_t vivim_sizeof(int which) {
         case 1: return sizeof(vivim_ssm_bwd_params);
         case 2: return sizeof(vivim_conv_fwd_params);
         case 3: return sizeof(vivim_conv_bwd_params);
+        case 4: return sizeof(vivim_dwconv_params);
+        case 5: return sizeof(vivim_dwconv_wgrad_params);
     }
     return 0;
 }
@@ -128,6 +132,39 @@ int vivim_causal_conv1d_bwd(const vivim_conv_bwd_params* p, void* stream) {
         return fail(VIVIM_ERR_UNSUPPORTED, "causal_conv1d_bwd not implemented for input type %d / weight type %d",
                     p->f.itype, p->f.wtype);
     return after_launch("causal_conv1d_bwd");
+}
+
+static int check_dw_dims(int batch, int depth, int height, int width, int channels, int kd, int itype) {
+    VCHECK(dtype_ok(itype));
+    VCHECK(batch > 0 && depth > 0 && height > 0 && width > 0 && channels > 0);
+    VCHECK(kd == 1 || kd == 3);
+    VCHECK(batch <= 65535);
+    return VIVIM_OK;
+}
+
+int vivim_dwconv_fwd(const vivim_dwconv_params* p, void* stream) {
+    VCHECK(p != nullptr);
+    if (int rc = check_dw_dims(p->batch, p->depth, p->height, p->width, p->channels, p->kd, p->itype)) return rc;
+    VCHECK(p->x && p->wt && p->y);
+    const int64_t cv = p->itype == VIVIM_F32 ? 4 : 8;
+    VCHECK(p->channels % cv == 0 && p->x_token_stride % cv == 0 && p->x_batch_stride % cv == 0 &&
+           p->y_token_stride % cv == 0 && p->y_batch_stride % cv == 0);
+    VCHECK((reinterpret_cast<uintptr_t>(p->x) & 15) == 0 && (reinterpret_cast<uintptr_t>(p->y) & 15) == 0);
+    if (!vivim::dwconv_fwd_dispatch(*p, static_cast<hipStream_t>(stream)))
+        return fail(VIVIM_ERR_UNSUPPORTED, "dwconv_fwd not implemented for input type %d", p->itype);
+    return after_launch("dwconv_fwd");
+}
+
+int vivim_dwconv_wgrad(const vivim_dwconv_wgrad_params* p, void* stream) {
+    VCHECK(p != nullptr);
+    if (int rc = check_dw_dims(p->batch, p->depth, p->height, p->width, p->channels, p->kd, p->itype)) return rc;
+    VCHECK(p->x && p->dy && p->dwt);
+    VCHECK(p->channels % 2 == 0 && p->x_token_stride % 2 == 0 && p->x_batch_stride % 2 == 0 &&
+           p->dy_token_stride % 2 == 0 && p->dy_batch_stride % 2 == 0);
+    VCHECK((reinterpret_cast<uintptr_t>(p->x) & 7) == 0 && (reinterpret_cast<uintptr_t>(p->dy) & 7) == 0);
+    if (!vivim::dwconv_wgrad_dispatch(*p, static_cast<hipStream_t>(stream)))
+        return fail(VIVIM_ERR_UNSUPPORTED, "dwconv_wgrad not implemented for input type %d", p->itype);
+    return after_launch("dwconv_wgrad");
 }
 
 }  // extern "C"

@@ -32,14 +32,15 @@ def recall_focused_loss(logits, targets, num_classes, gamma=2.0):
     return 0.4 * class_balanced_focal_loss(probs, onehot, gamma, alpha) + 0.6 * tversky_loss(probs, onehot)
 
 
-def build_model(num_classes=3, device="cuda", mamba_kwargs=None, drop_path_rate=0.2):
+def build_model(num_classes=3, device="cuda", mamba_kwargs=None, drop_path_rate=0.2, fast_backbone_dwconv=True):
     """Vivim with a randomly initialised SegFormer-b3 backbone (no hub access on the GPU box).  The two
     parameter groups that never receive a gradient in Vivim's forward -- the SegFormer 150-class classifier
     and the per-stage encoder layer norms (vivim.py:211-212, 325) -- are frozen so DDP needs no
     unused-parameter search."""
     from .vivim import Vivim, segformer_b3_random
     model = Vivim(in_chans=3, out_chans=num_classes, backbone=segformer_b3_random(),
-                  drop_path_rate=drop_path_rate, mamba_kwargs=mamba_kwargs)
+                  drop_path_rate=drop_path_rate, mamba_kwargs=mamba_kwargs,
+                  fast_backbone_dwconv=fast_backbone_dwconv)
     for p in model.decoder.classifier.parameters():
         p.requires_grad_(False)
     for p in model.encoder.downsample_layers.layer_norm.parameters():

@@ -13,6 +13,9 @@ Differences from the reference, all additive:
   * works with both SegFormer module layouts of `transformers` (4.x `encoder.patch_embeddings/block/
     layer_norm` + `decode_head.linear_c`, and 5.x `stages[i].{patch_embeddings,blocks,layer_norm}` +
     `decode_head.linear_projections`).
+  * the Mlp's depthwise Conv3d runs on the token-major HIP kernel (csrc/dwconv.hip) when the
+    tensor qualifies; `fast_backbone_dwconv=True` additionally routes the SegFormer Mix-FFN 3x3 depthwise convs
+    through the same kernel (same parameters, same math, state-dict keys unchanged).
   * timm is not required: DropPath / trunc_normal_ are the torch equivalents.
 """
 import math
@@ -21,6 +24,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import dwconv as _dw
 from .mamba_simple import Mamba
 
 
@@ -86,6 +90,9 @@ class DWConv(nn.Module):
 
     def forward(self, x, nf, H, W):
         B, _, C = x.shape
+        if _dw.supported(x, self.dwconv.weight):
+            # token-major HIP kernels (csrc/dwconv.hip): same math, no transposes, no MIOpen naive conv
+            return _dw.depthwise_conv_tokens(x, self.dwconv.weight, self.dwconv.bias, nf, H, W)
         x = self.dwconv(x.transpose(1, 2).view(B, C, nf, H, W))
         return x.flatten(2).transpose(1, 2)
 
@@ -141,6 +148,37 @@ def _encoder_parts(backbone):
             [s.layer_norm for s in seg.stages])
 
 
+class _TokenDWConv2d(nn.Module):
+    """Drop-in for transformers' SegformerDepthWiseConv (forward(hidden_states, height, width) on (B, H*W, C)
+    tokens): same `dwconv` nn.Conv2d parameters, but evaluated by the token-major HIP kernel (csrc/dwconv.hip)
+    instead of transpose -> MIOpen depthwise conv -> transpose.  Opt-in (mamba_block(fast_backbone_dwconv=True))."""
+
+    def __init__(self, hf_module):
+        super().__init__()
+        self.dwconv = hf_module.dwconv
+
+    def forward(self, hidden_states, height, width):
+        if _dw.supported(hidden_states, self.dwconv.weight):
+            return _dw.depthwise_conv_tokens(hidden_states, self.dwconv.weight, self.dwconv.bias, 1, height, width)
+        b, _, c = hidden_states.shape
+        y = self.dwconv(hidden_states.transpose(1, 2).view(b, c, height, width))
+        return y.flatten(2).transpose(1, 2)
+
+
+def _swap_backbone_dwconv(module):
+    """Replace every 3x3 depthwise conv wrapper inside the SegFormer Mix-FFNs (attribute `dwconv` holding a
+    module that itself owns a depthwise nn.Conv2d called `dwconv`)."""
+    n = 0
+    for m in module.modules():
+        inner = getattr(m, "dwconv", None)
+        conv = getattr(inner, "dwconv", None)
+        if isinstance(conv, nn.Conv2d) and conv.groups == conv.in_channels and conv.kernel_size == (3, 3) \
+                and conv.stride == (1, 1) and conv.padding == (1, 1) and not isinstance(inner, _TokenDWConv2d):
+            m.dwconv = _TokenDWConv2d(inner)
+            n += 1
+    return n
+
+
 class _Encoder(nn.Module):
     """Holds the SegFormer encoder pieces under the reference's attribute names."""
 
@@ -161,9 +199,12 @@ class mamba_block(nn.Module):
     """SegFormer encoder stages interleaved with MambaLayer stages (modeling/vivim.py:163-231)."""
 
     def __init__(self, backbone, in_chans=1, depths=[2, 2, 2, 2], dims=[64, 128, 320, 512],
-                 drop_path_rate=0.0, layer_scale_init_value=1e-6, out_indices=[0, 1, 2, 3], mamba_kwargs=None):
+                 drop_path_rate=0.0, layer_scale_init_value=1e-6, out_indices=[0, 1, 2, 3], mamba_kwargs=None,
+                 fast_backbone_dwconv=False):
         super().__init__()
         self.downsample_layers = _Encoder(backbone)
+        if fast_backbone_dwconv:
+            _swap_backbone_dwconv(self.downsample_layers)
         dp_rates = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths))]
         mk = mamba_kwargs or {}
         self.stages = nn.ModuleList()
@@ -216,7 +257,7 @@ class Vivim(nn.Module):
     def __init__(self, in_chans=3, out_chans=3, depths=[2, 2, 2, 2], feat_size=[64, 128, 320, 512],
                  drop_path_rate=0.2, layer_scale_init_value=1e-6, hidden_size: int = 768, norm_name="instance",
                  conv_block: bool = True, res_block: bool = True, spatial_dims=2, with_edge=False,
-                 dropout_rate=0.3, backbone=None, mamba_kwargs=None) -> None:
+                 dropout_rate=0.3, backbone=None, mamba_kwargs=None, fast_backbone_dwconv=False) -> None:
         super().__init__()
         self.hidden_size = hidden_size
         self.in_chans, self.out_chans = in_chans, out_chans
@@ -229,7 +270,8 @@ class Vivim(nn.Module):
             from transformers import SegformerForSemanticSegmentation
             backbone = SegformerForSemanticSegmentation.from_pretrained("nvidia/segformer-b3-finetuned-ade-512-512")
         self.encoder = mamba_block(backbone, in_chans, depths=depths, dims=feat_size,
-                                   drop_path_rate=drop_path_rate, mamba_kwargs=mamba_kwargs)
+                                   drop_path_rate=drop_path_rate, mamba_kwargs=mamba_kwargs,
+                                   fast_backbone_dwconv=fast_backbone_dwconv)
         self.decoder = backbone.decode_head
         self.feature_dropout = nn.Dropout2d(dropout_rate)
         self.out = nn.Conv2d(768, out_chans, kernel_size=1)
