@@ -79,37 +79,29 @@ def cpu_baseline(seconds_budget=20.0):
 
 def main():
     a = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from vivim_amd import _lib, dp
+    from vivim_amd.train_step import build_model, make_optimizer, synthetic_batch, train_step
+    world, rank, local_rank = dp.dist_env()
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)        # RCCL over xGMI
+    dp.init("nccl", dev)                                       # RCCL over xGMI when WORLD_SIZE > 1
     amp = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[a.dtype]
 
-    from vivim_amd import _lib
-    from vivim_amd.train_step import build_model, make_optimizer, synthetic_batch, train_step
     _lib.lib()                                                 # fail loudly if the HIP library is missing
 
     torch.manual_seed(a.seed)                                  # identical replicas
     model = build_model(a.num_classes, dev, mamba_kwargs={"d_state": a.d_state, "expand": a.expand},
                         fast_backbone_dwconv=not a.stock_backbone_dwconv)
-    step_model = model
-    if world > 1:
-        # bucketed all-reduce (25 MB) in reverse registration order: the stage-3/2 buckets are in flight
-        # while the long stage-0/1 backward scans still run.
-        step_model = torch.nn.parallel.DistributedDataParallel(
-            model, device_ids=[local_rank], bucket_cap_mb=25, gradient_as_bucket_view=True, static_graph=True)
+    # bucketed all-reduce (25 MB) in reverse registration order: the stage-3/2 buckets are in flight while the
+    # long stage-0/1 backward scans still run (vivim_amd/dp.py; identity at N = 1)
+    step_model = dp.wrap(model, dev)
     opt = make_optimizer(model)
-    clip, onehot = synthetic_batch(a.train_bs, a.clip_length, a.image_size, a.num_classes, dev, a.seed + rank)
+    clip, onehot = synthetic_batch(a.train_bs, a.clip_length, a.image_size, a.num_classes, dev,
+                                   dp.shard_seed(a.seed, rank))
 
     def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        dp.barrier(dev)
 
     for _ in range(a.warmup):
         train_step(step_model, opt, clip, onehot, a.num_classes, amp)
@@ -121,10 +113,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     records = _lib.profile_end()
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = dp.max_over_ranks(elapsed, dev)
     assert torch.isfinite(loss), "non-finite loss"
 
     if rank == 0:

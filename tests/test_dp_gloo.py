@@ -1,0 +1,74 @@
+"""CPU, world_size 2, gloo: the data-parallel plumbing (vivim_amd/dp.py) that bench.py uses around the train
+step -- rank-offset shards, DDP gradient averaging equal to the large-batch gradient, max-over-ranks timing,
+and that freezing the never-used parameters leaves a graph DDP accepts without unused-parameter search."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class TinyVivimShape(torch.nn.Module):
+    """Same *structure* as Vivim for DDP purposes: used trunk + two parameter groups the forward never touches."""
+
+    def __init__(self):
+        super().__init__()
+        self.trunk = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.GELU(), torch.nn.Linear(16, 3))
+        self.decoder = torch.nn.Module()
+        self.decoder.classifier = torch.nn.Linear(16, 150)           # never used (vivim.py:325)
+        self.encoder = torch.nn.Module()
+        self.encoder.downsample_layers = torch.nn.Module()
+        self.encoder.downsample_layers.layer_norm = torch.nn.ModuleList([torch.nn.LayerNorm(16)])   # never used
+
+    def forward(self, x):
+        return self.trunk(x)
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from vivim_amd import dp
+    w, r, _ = dp.init(backend="gloo")
+    assert (w, r) == (world, rank)
+    torch.manual_seed(7)                                   # identical replicas
+    model = TinyVivimShape()
+    assert dp.freeze_unused(model) == 4
+    ddp = dp.wrap(model)
+    g = torch.Generator().manual_seed(dp.shard_seed(100, rank))
+    x, y = torch.randn(4, 8, generator=g), torch.randn(4, 3, generator=g)
+    loss = torch.nn.functional.mse_loss(ddp(x), y)
+    loss.backward()
+    dp.barrier()
+    t = dp.max_over_ranks(1.0 + rank)
+    grads = torch.cat([p.grad.flatten() for p in model.parameters() if p.requires_grad])
+    torch.save({"grads": grads, "x": x, "y": y, "t": t}, os.path.join(out, f"r{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+def test_ddp_gloo_world2(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"r{i}.pt") for i in range(2))
+    assert not torch.equal(r0["x"], r1["x"])                               # different shards
+    assert torch.allclose(r0["grads"], r1["grads"])                        # all-reduced gradients agree
+    assert r0["t"] == r1["t"] == 2.0                                        # max over ranks
+    torch.manual_seed(7)
+    ref = TinyVivimShape()
+    x, y = torch.cat([r0["x"], r1["x"]]), torch.cat([r0["y"], r1["y"]])
+    torch.nn.functional.mse_loss(ref.trunk(x), y).backward()
+    want = torch.cat([p.grad.flatten() for p in ref.trunk.parameters()])
+    assert torch.allclose(r0["grads"], want, atol=1e-6)                    # = gradient of the global batch
+
+
+def test_single_process_helpers_are_identity():
+    sys.path.insert(0, ROOT)
+    from vivim_amd import dp
+    m = torch.nn.Linear(2, 2)
+    assert dp.wrap(m) is m and dp.max_over_ranks(3.5) == 3.5 and dp.shard_seed(1, 3) == 4

@@ -41,10 +41,8 @@ def build_model(num_classes=3, device="cuda", mamba_kwargs=None, drop_path_rate=
     model = Vivim(in_chans=3, out_chans=num_classes, backbone=segformer_b3_random(),
                   drop_path_rate=drop_path_rate, mamba_kwargs=mamba_kwargs,
                   fast_backbone_dwconv=fast_backbone_dwconv)
-    for p in model.decoder.classifier.parameters():
-        p.requires_grad_(False)
-    for p in model.encoder.downsample_layers.layer_norm.parameters():
-        p.requires_grad_(False)
+    from .dp import freeze_unused
+    freeze_unused(model)
     return model.to(device)
 
 
