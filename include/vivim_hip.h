@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define VIVIM_ABI_VERSION 2
+#define VIVIM_ABI_VERSION 3
 
 typedef enum { VIVIM_F32 = 0, VIVIM_F16 = 1, VIVIM_BF16 = 2 } vivim_dtype_t;
 
@@ -79,6 +79,9 @@ typedef struct {
     void *x;                    /* (batch, dim, n_chunks, dstate) f32 contiguous: state after each chunk of
                                    vivim_scan_chunk_len() tokens; x[:, :, -1, :] is the final state
                                    (the reference's x[:, :, -1, 1::2], selective_scan_interface.py:40) */
+    void *workspace;            /* forward only: device scratch of >= vivim_scan_fwd_workspace_bytes() bytes or NULL
+                                   (NULL selects a kernel that needs none); ignored inside vivim_ssm_bwd_params.f */
+    int64_t workspace_bytes;
 } vivim_ssm_fwd_params;
 
 /* ---- selective scan, backward (selective_scan.h:71-101) ------------------------------------- */
@@ -175,6 +178,9 @@ int vivim_scan_chunk_len(int itype);
 /* Scratch the backward wants for splitting the token axis over workgroups (carries of the reverse
  * recurrence per (batch, channel, segment, state)); depends only on the sizes in `f`. */
 size_t vivim_scan_bwd_workspace_bytes(const vivim_ssm_fwd_params *f);
+/* Scratch the forward wants for its token-axis split (per-segment end states); 0 when the shape takes a kernel
+ * that needs none. */
+size_t vivim_scan_fwd_workspace_bytes(const vivim_ssm_fwd_params *f);
 
 int vivim_selective_scan_fwd(const vivim_ssm_fwd_params *p, void *stream);
 int vivim_selective_scan_bwd(const vivim_ssm_bwd_params *p, void *stream);

@@ -30,7 +30,7 @@ def test_struct_layouts_match():
                                 _lib.DwConvParams, _lib.DwConvWgradParams)):
         assert L.vivim_sizeof(which) == ctypes.sizeof(st)
     assert L.vivim_sizeof(99) == 0
-    assert L.vivim_abi_version() == 2
+    assert L.vivim_abi_version() == 3
     assert L.vivim_scan_chunk_len(_lib.F32) > 0 and L.vivim_scan_chunk_len(_lib.BF16) % 64 == 0
 
 

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
+#include "../vivim_amd/csrc/scan_fwd_chan.hip"
 #include "../vivim_amd/csrc/scan_fwd.hip"
 #include "../vivim_amd/csrc/scan_bwd.hip"
 
@@ -41,6 +42,7 @@ int main(int argc, char** argv) {
     p.A_d_stride = N; p.A_dstate_stride = 1;
     p.B_batch_stride = p.C_batch_stride = (int64_t)N * L; p.B_group_stride = p.C_group_stride = (int64_t)N * L;
     p.B_dstate_stride = p.C_dstate_stride = L;
+    p.workspace_bytes = (int64_t)vivim::scan_fwd_workspace_bytes(p); if (p.workspace_bytes) CK(hipMalloc(&p.workspace, p.workspace_bytes));
     p.u = u; p.delta = dl; p.A = A; p.B = Bm; p.C = Cm; p.D = Dv; p.delta_bias = bias; p.z = z; p.out = out; p.out_z = outz; p.x = x;
 
     const int nstamp = 2 * vivim::kStampWaves * vivim::kStampSteps * vivim::kStampSlots;

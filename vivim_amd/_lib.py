@@ -25,7 +25,8 @@ class SsmFwdParams(ctypes.Structure):
                               "out_z_batch_stride", "out_z_d_stride", "A_d_stride", "A_dstate_stride",
                               "B_batch_stride", "B_group_stride", "B_dstate_stride",
                               "C_batch_stride", "C_group_stride", "C_dstate_stride")]
-        + [(n, vp) for n in ("u", "delta", "A", "B", "C", "D", "delta_bias", "z", "out", "out_z", "x")]
+        + [(n, vp) for n in ("u", "delta", "A", "B", "C", "D", "delta_bias", "z", "out", "out_z", "x", "workspace")]
+        + [("workspace_bytes", i64)]
     )
 
 
@@ -79,7 +80,7 @@ class DwConvWgradParams(ctypes.Structure):
 
 
 EXPORTS = ("vivim_abi_version", "vivim_last_error", "vivim_scan_chunk_len", "vivim_sizeof",
-           "vivim_scan_bwd_workspace_bytes",
+           "vivim_scan_bwd_workspace_bytes", "vivim_scan_fwd_workspace_bytes",
            "vivim_selective_scan_fwd", "vivim_selective_scan_bwd",
            "vivim_causal_conv1d_fwd", "vivim_causal_conv1d_bwd", "vivim_dwconv_fwd", "vivim_dwconv_wgrad")
 
@@ -106,15 +107,16 @@ def lib():
         L.vivim_last_error.restype = ctypes.c_char_p
         L.vivim_sizeof.restype = ctypes.c_size_t
         L.vivim_sizeof.argtypes = [ctypes.c_int]
-        L.vivim_scan_bwd_workspace_bytes.restype = ctypes.c_size_t
-        L.vivim_scan_bwd_workspace_bytes.argtypes = [ctypes.POINTER(SsmFwdParams)]
+        for fn in (L.vivim_scan_bwd_workspace_bytes, L.vivim_scan_fwd_workspace_bytes):
+            fn.restype = ctypes.c_size_t
+            fn.argtypes = [ctypes.POINTER(SsmFwdParams)]
         for name, st in (("vivim_selective_scan_fwd", SsmFwdParams), ("vivim_selective_scan_bwd", SsmBwdParams),
                          ("vivim_causal_conv1d_fwd", ConvFwdParams), ("vivim_causal_conv1d_bwd", ConvBwdParams),
                          ("vivim_dwconv_fwd", DwConvParams), ("vivim_dwconv_wgrad", DwConvWgradParams)):
             fn = getattr(L, name)
             fn.argtypes = [ctypes.POINTER(st), vp]
             fn.restype = ctypes.c_int
-        if L.vivim_abi_version() != 2:
+        if L.vivim_abi_version() != 3:
             raise ImportError("libvivim_hip.so ABI version mismatch")
         for which, st in enumerate((SsmFwdParams, SsmBwdParams, ConvFwdParams, ConvBwdParams, DwConvParams,
                                     DwConvWgradParams)):
@@ -155,37 +157,49 @@ def algorithmic_bytes(name, P):
 
 
 _profile = None
+_event_pool = []
+_PROFILED = ("vivim_selective_scan_fwd", "vivim_selective_scan_bwd", "vivim_causal_conv1d_fwd",
+             "vivim_causal_conv1d_bwd")
 
 
-def profile_begin():
-    """Start recording one (name, algorithmic bytes, start event, end event) tuple per C-ABI call; the
-    events are recorded on the stream the kernel is launched on (torch's current stream)."""
+def profile_begin(all_kernels=False):
+    """Start recording one (name, algorithmic bytes, start event, end event) tuple per C-ABI call of the hot-path
+    kernels (every kernel with all_kernels=True); events are recorded on the stream the kernel is launched on
+    (torch's current stream) and come from a reusable pool, so the timed region pays two hipEventRecord per call."""
     global _profile
-    _profile = []
+    _profile = ([], bool(all_kernels))
 
 
 def profile_end():
     """Stop recording; -> list of (name, bytes, seconds) after synchronising the recorded events."""
     global _profile
-    rec, _profile = _profile or [], None
+    rec = _profile[0] if _profile else []
+    _profile = None
     out = []
     for name, nbytes, e0, e1 in rec:
         e1.synchronize()
         out.append((name, nbytes, e0.elapsed_time(e1) * 1e-3))
+        _event_pool.extend((e0, e1))
     return out
+
+
+def _event():
+    if _event_pool:
+        return _event_pool.pop()
+    import torch
+    return torch.cuda.Event(enable_timing=True)
 
 
 def call(name, params, stream):
     """Enqueue one entry point on `stream` (int hipStream_t); RuntimeError on a nonzero return,
     like the TORCH_CHECKs of the reference bindings."""
     L = lib()
-    if _profile is not None:
-        import torch
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if _profile is not None and (_profile[1] or name in _PROFILED):
+        e0, e1 = _event(), _event()
         e0.record()
         rc = getattr(L, name)(ctypes.byref(params), vp(stream))
         e1.record()
-        _profile.append((name, algorithmic_bytes(name, params), e0, e1))
+        _profile[0].append((name, algorithmic_bytes(name, params), e0, e1))
     else:
         rc = getattr(L, name)(ctypes.byref(params), vp(stream))
     if rc != 0:

@@ -15,6 +15,7 @@ bool dwconv_wgrad_dispatch(const vivim_dwconv_wgrad_params&, hipStream_t);
 bool ssm_bwd_dispatch(const vivim_ssm_bwd_params&, hipStream_t);
 int scan_chunk_len(int itype);
 size_t scan_bwd_workspace_bytes(const vivim_ssm_fwd_params&);
+size_t scan_fwd_workspace_bytes(const vivim_ssm_fwd_params&);
 }  // namespace vivim
 
 static thread_local char g_err[512] = "";
@@ -67,6 +68,9 @@ const char* vivim_last_error(void) { return g_err; }
 int vivim_scan_chunk_len(int itype) { return vivim::scan_chunk_len(itype); }
 size_t vivim_scan_bwd_workspace_bytes(const vivim_ssm_fwd_params* f) {
     return f ? vivim::scan_bwd_workspace_bytes(*f) : 0;
+}
+size_t vivim_scan_fwd_workspace_bytes(const vivim_ssm_fwd_params* f) {
+    return f ? vivim::scan_fwd_workspace_bytes(*f) : 0;
 }
 size_t vivim_sizeof(int which) {
     switch (which) {

@@ -405,7 +405,7 @@ static bool try_fwd_nsplit(const vivim_ssm_fwd_params& p, hipStream_t stream) {
     // 512-token steps (K=8) halve the per-step fixed cost; 256-token steps (K=4) need 100 instead of 160 VGPRs,
     // so several workgroups share a CU -- better once there are enough workgroups to fill the chip twice.
     const int64_t nwg = (int64_t)((p.dim / p.n_groups + kNsR - 1) / kNsR) * p.n_groups * p.batch;
-    int variant = forced ? forced : (nwg >= 512 ? 2 : 1);
+    int variant = (forced && forced != 5) ? forced : (nwg >= 512 ? 2 : 1);
     switch (variant) {
         case 2:  launch_fwd_nsplit<T, 4, 8, 2>(p, stream); break;     // K=4
         case 3:  return false;                                         // generic kernel (tuning only)
@@ -436,7 +436,10 @@ static void launch_fwd(const vivim_ssm_fwd_params& p, hipStream_t stream) {
 int scan_chunk_len(int) { return kChunk; }
 static_assert(kWave * 4 == kChunk, "generic kernel step must equal the checkpoint chunk");
 
+bool try_fwd_chan(const vivim_ssm_fwd_params& p, hipStream_t stream);   // scan_fwd_chan.hip
+
 bool ssm_fwd_dispatch(const vivim_ssm_fwd_params& p, hipStream_t s) {
+    if (try_fwd_chan(p, s)) return true;               // lanes = channels (dstate 16, aligned, workspace given)
     switch (p.itype) {
         case VIVIM_F32: if (!try_fwd_nsplit<float>(p, s)) launch_fwd<float, 4, 2>(p, s); return true;
         case VIVIM_F16: if (!try_fwd_nsplit<f16_t>(p, s)) launch_fwd<f16_t, 4, 2>(p, s); return true;

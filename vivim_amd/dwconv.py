@@ -2,6 +2,8 @@
 MambaLayer's Mlp (`DWConv`, modeling/vivim.py:57-68 -- nn.Conv3d(dim, dim, 3, 1, 1, groups=dim) applied to
 x.transpose(1, 2).view(B, C, nf, H, W)) without the transposes, on the gfx950 kernels of csrc/dwconv.hip.
 SURVEY.md section 8f row 4.  Same parameters as the nn.Conv3d / nn.Conv2d it replaces (weight (C,1,[kd,]3,3))."""
+import os
+
 import torch
 
 from . import _lib
@@ -11,7 +13,7 @@ _DT = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF
 
 def supported(x, weight):
     """True when the kernels apply: CUDA tensor, channels contiguous, 3x3(x3) taps, aligned channel count."""
-    if not (x.is_cuda and x.dim() == 3 and x.dtype in _DT and x.stride(2) == 1):
+    if os.environ.get("VIVIM_NO_DWCONV") or not (x.is_cuda and x.dim() == 3 and x.dtype in _DT and x.stride(2) == 1):
         return False
     cv = 16 // x.element_size()
     ks = tuple(weight.shape[2:])

@@ -103,6 +103,10 @@ def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus):
     if out_z is not None:
         P.out_z = out_z.data_ptr()
         P.out_z_batch_stride, P.out_z_d_stride = out_z.stride(0), out_z.stride(1)
+    ws_bytes = _lib.lib().vivim_scan_fwd_workspace_bytes(P)
+    if ws_bytes:
+        workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=u.device)
+        P.workspace, P.workspace_bytes = workspace.data_ptr(), ws_bytes
     with torch.cuda.device(u.device):
         _lib.call("vivim_selective_scan_fwd", P, torch.cuda.current_stream().cuda_stream)
     return [out, x] + ([out_z] if out_z is not None else [])

@@ -18,17 +18,22 @@ def tversky_loss(probs, onehot, alpha=0.3, beta=0.7, smooth=1e-6):
 
 def class_balanced_focal_loss(probs, onehot, gamma=2.0, alpha=(0.05, 0.475, 0.475)):
     """multiclass_training_folds.py:363-423 with explicit alpha."""
-    a = torch.tensor(alpha, device=probs.device, dtype=probs.dtype)[None, :, None, None]
+    a = alpha if torch.is_tensor(alpha) else torch.tensor(alpha, device=probs.device, dtype=probs.dtype)
+    a = a[None, :, None, None]
     weight = onehot * (1 - probs) ** gamma + (1 - onehot) * probs ** gamma
     bce = -onehot * torch.log(probs + 1e-6) - (1 - onehot) * torch.log(1 - probs + 1e-6)
     return (a * weight * bce).mean(dim=(0, 2, 3)).sum()
 
 
-def recall_focused_loss(logits, targets, num_classes, gamma=2.0):
-    """0.4 * focal + 0.6 * tversky (multiclass_training_folds.py:339-361). logits (N,C,H,W); targets (N,H,W)."""
+def recall_focused_loss(logits, targets, num_classes, gamma=2.0, onehot=None, alpha=None):
+    """0.4 * focal + 0.6 * tversky (multiclass_training_folds.py:339-361). logits (N,C,H,W); targets (N,H,W).
+    `onehot` (N,C,H,W float) and `alpha` (device tensor) may be passed pre-built (graph capture: no host->device
+    copy may happen inside the captured region)."""
     probs = F.softmax(logits.float(), dim=1)
-    onehot = F.one_hot(targets.long(), num_classes).permute(0, 3, 1, 2).float()
-    alpha = (0.05, 0.475, 0.475) if num_classes == 3 else tuple([1.0 / num_classes] * num_classes)
+    if onehot is None:
+        onehot = F.one_hot(targets.long(), num_classes).permute(0, 3, 1, 2).float()
+    if alpha is None:
+        alpha = (0.05, 0.475, 0.475) if num_classes == 3 else tuple([1.0 / num_classes] * num_classes)
     return 0.4 * class_balanced_focal_loss(probs, onehot, gamma, alpha) + 0.6 * tversky_loss(probs, onehot)
 
 
@@ -46,9 +51,9 @@ def build_model(num_classes=3, device="cuda", mamba_kwargs=None, drop_path_rate=
     return model.to(device)
 
 
-def make_optimizer(model, lr=1e-4, weight_decay=1e-2):
+def make_optimizer(model, lr=1e-4, weight_decay=1e-2, capturable=False):
     return torch.optim.AdamW((p for p in model.parameters() if p.requires_grad), lr=lr, betas=(0.9, 0.999),
-                             weight_decay=weight_decay)
+                             weight_decay=weight_decay, capturable=capturable)
 
 
 def synthetic_batch(batch, clip_length, image_size, num_classes, device, seed):
