@@ -182,6 +182,12 @@ size_t vivim_scan_bwd_workspace_bytes(const vivim_ssm_fwd_params *f);
  * that needs none. */
 size_t vivim_scan_fwd_workspace_bytes(const vivim_ssm_fwd_params *f);
 
+/* Kernel-selection override for tuning and tests: which = 0 forward scan (0 automatic, 1 n-split K=8, 2 n-split K=4,
+ * 3 generic, 5 lanes=channels), which = 1 backward scan (0 automatic, 3 generic).  Returns the previous value, -1 on a
+ * bad argument.  Initial values come from VIVIM_FWD_VARIANT / VIVIM_BWD_VARIANT.  The forward workspace size depends on
+ * the forward setting: query it after changing it. */
+int vivim_set_tuning(int which, int value);
+
 int vivim_selective_scan_fwd(const vivim_ssm_fwd_params *p, void *stream);
 int vivim_selective_scan_bwd(const vivim_ssm_bwd_params *p, void *stream);
 int vivim_causal_conv1d_fwd(const vivim_conv_fwd_params *p, void *stream);

@@ -82,3 +82,12 @@ def test_product_never_imports_oracle():
                     if re.search(r"^\s*(from|import)\s+oracle\b|ssm_oracle|ref_torch", src, flags=re.M):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_tuning_roundtrip():
+    """vivim_set_tuning returns the previous value and rejects bad arguments (no GPU needed)."""
+    L = _lib.lib()
+    prev = L.vivim_set_tuning(0, 5)
+    assert prev >= 0
+    assert L.vivim_set_tuning(0, prev) == 5
+    assert L.vivim_set_tuning(2, 0) == -1 and L.vivim_set_tuning(0, -3) == -1

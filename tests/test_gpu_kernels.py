@@ -275,6 +275,49 @@ def test_scan_optional_arguments(has_z, has_D, has_bias, softplus, cuda, ops):
     _check_scan(_rand_scan(gen, 2, 12, 16, 700, 1, torch.float32, cuda, has_z, has_D, has_bias, softplus), ss)
 
 
+# Every forward / backward kernel family must agree with the oracle, not only the one the dispatcher prefers:
+# vivim_set_tuning (include/vivim_hip.h) pins the family for the duration of a test.
+FWD_VARIANTS = {"auto": 0, "nsplit_k8": 1, "nsplit_k4": 2, "generic": 3, "channels": 5}
+BWD_VARIANTS = {"auto": 0, "generic": 3}
+
+
+@pytest.fixture
+def tuning():
+    from vivim_amd import _lib
+    L = _lib.lib()
+    prev = []
+
+    def pin(fwd=0, bwd=0):
+        prev.append((L.vivim_set_tuning(0, fwd), L.vivim_set_tuning(1, bwd)))
+
+    yield pin
+    if prev:
+        L.vivim_set_tuning(0, prev[0][0])
+        L.vivim_set_tuning(1, prev[0][1])
+
+
+@pytest.mark.parametrize("fwd", list(FWD_VARIANTS))
+@pytest.mark.parametrize("bwd", list(BWD_VARIANTS))
+@pytest.mark.parametrize("dtype,batch,dim,L,G", [(torch.bfloat16, 3, 128, 2048, 1), (torch.float32, 2, 64, 1288, 1),
+                                                (torch.float16, 2, 256, 320, 2), (torch.bfloat16, 1, 192, 8, 1)])
+def test_scan_kernel_families(fwd, bwd, dtype, batch, dim, L, G, cuda, ops, tuning):
+    """Vivim-shaped problems (dstate 16, whole 64-channel blocks, aligned rows) are eligible for every family:
+    n-split K=8 / K=4, lanes=channels (token-axis segments + carry kernel), generic; fast / generic backward."""
+    ss, _ = ops
+    tuning(FWD_VARIANTS[fwd], BWD_VARIANTS[bwd])
+    gen = torch.Generator().manual_seed(dim + L)
+    _check_scan(_rand_scan(gen, batch, dim, 16, L, G, dtype, cuda, init="module"), ss)
+
+
+@pytest.mark.parametrize("fwd", ["nsplit_k8", "channels"])
+def test_scan_kernel_families_strided_long(fwd, cuda, ops, tuning):
+    """(L, B*L, 1)-strided rows, many token-axis segments (L = 20480: S > 1 in the channels kernels)."""
+    ss, _ = ops
+    tuning(FWD_VARIANTS[fwd], 0)
+    gen = torch.Generator().manual_seed(11)
+    _check_scan(_rand_scan(gen, 3, 128, 16, 20480, 1, torch.bfloat16, cuda, strided=True, init="module"), ss)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_scan_vivim_strides(dtype, cuda, ops):
     """(L, B*L, 1)-strided u / delta / z / dout as produced by mamba_simple.py:204-208; out inherits

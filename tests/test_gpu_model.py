@@ -86,3 +86,22 @@ def test_mamba_layer_and_vivim_train_step(cuda):
     assert torch.isfinite(loss)
     grads = [p.grad for n, p in model.named_parameters() if "mamba" in n]
     assert grads and all(g is not None and torch.isfinite(g).all() for g in grads)
+
+
+def test_vivim_inference_matches_training_graph(cuda):
+    """no_grad / eval forward at the benchmark's geometry (256x256, clip 5, batch 3): the inference path must run
+    and give the same logits as the autograd-recording forward in eval mode (it once died with a GPU memory fault in
+    a library GEMM of the decode head; vivim.py:decode keeps the reference's nn.Conv2d there)."""
+    from vivim_amd.train_step import build_model, synthetic_batch
+    torch.manual_seed(0)
+    model = build_model(3, cuda, mamba_kwargs={"d_state": 16, "expand": 2}).eval()
+    clip, _ = synthetic_batch(3, 5, 256, 3, cuda, 7)
+    torch.manual_seed(1)                        # decode() draws CPU coin flips even in eval (vivim.py:310-312)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        a = model(clip)
+    torch.manual_seed(1)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        b = model(clip)
+    torch.cuda.synchronize()
+    assert a.shape == (15, 3, 256, 256) and torch.isfinite(a).all()
+    assert (a.float() - b.float()).abs().max() <= 2e-2 * b.float().abs().max()

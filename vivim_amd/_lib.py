@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.path.join(CSRC, "libvivim_hip.so")
+SO_PATH = os.environ.get("VIVIM_LIB") or os.path.join(CSRC, "libvivim_hip.so")   # VIVIM_LIB: A/B builds
 
 i32, i64, vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
 
@@ -80,7 +80,7 @@ class DwConvWgradParams(ctypes.Structure):
 
 
 EXPORTS = ("vivim_abi_version", "vivim_last_error", "vivim_scan_chunk_len", "vivim_sizeof",
-           "vivim_scan_bwd_workspace_bytes", "vivim_scan_fwd_workspace_bytes",
+           "vivim_scan_bwd_workspace_bytes", "vivim_scan_fwd_workspace_bytes", "vivim_set_tuning",
            "vivim_selective_scan_fwd", "vivim_selective_scan_bwd",
            "vivim_causal_conv1d_fwd", "vivim_causal_conv1d_bwd", "vivim_dwconv_fwd", "vivim_dwconv_wgrad")
 
@@ -107,6 +107,8 @@ def lib():
         L.vivim_last_error.restype = ctypes.c_char_p
         L.vivim_sizeof.restype = ctypes.c_size_t
         L.vivim_sizeof.argtypes = [ctypes.c_int]
+        L.vivim_set_tuning.restype = ctypes.c_int
+        L.vivim_set_tuning.argtypes = [ctypes.c_int, ctypes.c_int]
         for fn in (L.vivim_scan_bwd_workspace_bytes, L.vivim_scan_fwd_workspace_bytes):
             fn.restype = ctypes.c_size_t
             fn.argtypes = [ctypes.POINTER(SsmFwdParams)]
@@ -190,6 +192,54 @@ def _event():
     return torch.cuda.Event(enable_timing=True)
 
 
+# ---- VIVIM_GUARD=1: debug mode that brackets every buffer the wrappers allocate for a kernel to write with canary
+# bytes and verifies them (device sync) after each launch -- finds out-of-bounds writes without waiting for a fault.
+GUARD = os.environ.get("VIVIM_GUARD", "0") not in ("0", "")
+_GUARD_BYTES = 1 << 16
+_guards = []
+
+
+def _guarded_storage(nbytes, device):
+    import torch
+    buf = torch.full((nbytes + 2 * _GUARD_BYTES,), 0xA5, dtype=torch.uint8, device=device)
+    _guards.append(buf)
+    return buf[_GUARD_BYTES:_GUARD_BYTES + nbytes]
+
+
+def empty(shape, dtype, device):
+    """torch.empty, or its canary-bracketed twin under VIVIM_GUARD=1."""
+    import torch
+    if not GUARD:
+        return torch.empty(shape, dtype=dtype, device=device)
+    n = 1
+    for d in shape:
+        n *= d
+    return _guarded_storage(n * torch.empty((), dtype=dtype).element_size(), device).view(dtype).view(shape)
+
+
+def empty_like(t):
+    """torch.empty_like (dense, same strides), or its canary-bracketed twin under VIVIM_GUARD=1."""
+    import torch
+    if not GUARD:
+        return torch.empty_like(t)
+    ref = torch.empty_like(t)                               # for its strides
+    flat = _guarded_storage(t.numel() * t.element_size(), t.device).view(t.dtype)
+    return flat.as_strided(ref.shape, ref.stride())
+
+
+def check_guards(what):
+    import torch
+    torch.cuda.synchronize()
+    for buf in _guards:
+        lo, hi = buf[:_GUARD_BYTES], buf[-_GUARD_BYTES:]
+        if not (bool((lo == 0xA5).all()) and bool((hi == 0xA5).all())):
+            nlo, nhi = int((lo != 0xA5).sum()), int((hi != 0xA5).sum())
+            _guards.clear()
+            raise RuntimeError(f"VIVIM_GUARD: {what} wrote outside a {buf.numel() - 2 * _GUARD_BYTES}-byte buffer "
+                               f"({nlo} bytes below, {nhi} bytes above)")
+    _guards.clear()
+
+
 def call(name, params, stream):
     """Enqueue one entry point on `stream` (int hipStream_t); RuntimeError on a nonzero return,
     like the TORCH_CHECKs of the reference bindings."""
@@ -204,3 +254,5 @@ def call(name, params, stream):
         rc = getattr(L, name)(ctypes.byref(params), vp(stream))
     if rc != 0:
         raise RuntimeError(L.vivim_last_error().decode())
+    if GUARD:
+        check_guards(name)

@@ -48,9 +48,9 @@ def _fill(P, x, weight, bias_, silu_activation, dims):
 def causal_conv1d_fwd(x, weight, bias_, silu_activation):
     """-> out (empty_like(x)); causal_conv1d.cpp:130-189."""
     dims = _checks(x, weight, bias_)
-    out = torch.empty_like(x)
+    out = _lib.empty_like(x)
     if out.stride(2) != 1:       # empty_like of an exotic view may not keep unit seqlen stride
-        out = torch.empty(x.shape, device=x.device, dtype=x.dtype)
+        out = _lib.empty(tuple(x.shape), x.dtype, x.device)
     P = _lib.ConvFwdParams()
     _fill(P, x, weight, bias_, silu_activation, dims)
     P.out = out.data_ptr()
@@ -73,9 +73,9 @@ def causal_conv1d_bwd(x, weight, bias_, dout, dx_, silu_activation):
                and dx_.stride(2) == 1, "dx must match x and have stride(2) == 1")
         dx = dx_
     else:
-        dx = torch.empty_like(x)
+        dx = _lib.empty_like(x)
         if dx.stride(2) != 1:
-            dx = torch.empty(x.shape, device=x.device, dtype=x.dtype)
+            dx = _lib.empty(tuple(x.shape), x.dtype, x.device)
     dweight = torch.zeros(weight.shape, device=x.device, dtype=torch.float32)
     dbias = torch.zeros(dim, device=x.device, dtype=torch.float32) if bias_ is not None else None
     P = _lib.ConvBwdParams()

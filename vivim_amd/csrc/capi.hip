@@ -61,8 +61,30 @@ static int check_ssm_fwd(const vivim_ssm_fwd_params* p, bool is_bwd) {
     return VIVIM_OK;
 }
 
+namespace vivim {
+static int g_tune[2] = {-1, -1};     // host-side; accessed with relaxed atomics
+static int tuning_get(int which, const char* env) {
+    int v = __atomic_load_n(&g_tune[which], __ATOMIC_RELAXED);
+    if (v < 0) {
+        const char* e = getenv(env);
+        v = e ? atoi(e) : 0;
+        if (v < 0) v = 0;
+        __atomic_store_n(&g_tune[which], v, __ATOMIC_RELAXED);
+    }
+    return v;
+}
+int tuning_fwd_variant() { return tuning_get(0, "VIVIM_FWD_VARIANT"); }
+int tuning_bwd_variant() { return tuning_get(1, "VIVIM_BWD_VARIANT"); }
+}  // namespace vivim
+
 extern "C" {
 
+int vivim_set_tuning(int which, int value) {
+    if (which < 0 || which > 1 || value < 0) return -1;
+    const int prev = which == 0 ? vivim::tuning_fwd_variant() : vivim::tuning_bwd_variant();
+    __atomic_store_n(&vivim::g_tune[which], value, __ATOMIC_RELAXED);
+    return prev;
+}
 int vivim_abi_version(void) { return VIVIM_ABI_VERSION; }
 const char* vivim_last_error(void) { return g_err; }
 int vivim_scan_chunk_len(int itype) { return vivim::scan_chunk_len(itype); }

@@ -6,6 +6,13 @@
 
 namespace vivim {
 
+// Kernel-selection overrides (capi.hip): 0 = automatic.  Initialised from VIVIM_FWD_VARIANT / VIVIM_BWD_VARIANT,
+// changed at run time through vivim_set_tuning() (tests and tools sweep the variants in one process).
+//   forward : 1 n-split K=8, 2 n-split K=4, 3 generic, 5 lanes=channels (needs the forward workspace)
+//   backward: 3 generic
+int tuning_fwd_variant();
+int tuning_bwd_variant();
+
 constexpr int kWave = 64;
 constexpr int kChunk = 256;   // tokens per row of the checkpoint tensor x (contract between fwd and bwd kernels)
 constexpr float kLog2e = 1.4426950408889634f;
@@ -25,11 +32,13 @@ __device__ __forceinline__ float sigmoidf_fast(float x) { return fast_rcp(1.0f +
 // softplus with the reference's threshold (fwd_kernel.cuh:155: x <= 20 ? log1p(exp(x)) : x).
 // log1p(e) via Kahan's correction so that small e keeps full relative precision.
 __device__ __forceinline__ float softplus_ref(float x) {
-    if (x > 20.0f) return x;
-    const float e = fast_exp(x);
+    // Branch-free (selects only): divergent branches in the scan inner loops split the scheduling regions and
+    // force s_waitcnt drains.  min() keeps exp finite on the x > 20 side whose result is discarded.
+    const float e = fast_exp(fminf(x, 20.0f));
     const float w = 1.0f + e;
     const float d = w - 1.0f;
-    return d == 0.0f ? e : fast_log(w) * (e * fast_rcp(d));
+    const float r = fast_log(w) * (e * fast_rcp(d == 0.0f ? 1.0f : d));
+    return x > 20.0f ? x : (d == 0.0f ? e : r);
 }
 
 // ---- element conversion ----

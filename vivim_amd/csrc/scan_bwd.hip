@@ -672,8 +672,7 @@ static bool try_bwd_fast(const vivim_ssm_bwd_params& p, hipStream_t stream) {
     const vivim_ssm_fwd_params& f = p.f;
     constexpr int K = 4;
     if (!f.is_variable_B || !f.is_variable_C || f.dstate > 64 || f.x == nullptr) return false;
-    static const int forced = [] { const char* e = getenv("VIVIM_BWD_VARIANT"); return e ? atoi(e) : 0; }();
-    if (forced == 3) return false;
+    if (tuning_bwd_variant() == 3) return false;
     // unconditional K-element vectors: rows aligned to the vector size, seqlen a whole number of lanes
     const int64_t vb = K * (int64_t)sizeof(T) >= 16 ? 16 : K * (int64_t)sizeof(T);
     const int64_t epv = vb / (int64_t)sizeof(T);
@@ -689,8 +688,13 @@ static bool try_bwd_fast(const vivim_ssm_bwd_params& p, hipStream_t stream) {
                 !st(f.out_batch_stride) || !st(f.out_d_stride) || !st(p.dz_batch_stride) || !st(p.dz_d_stride) ||
                 (f.out_z && (!al(f.out_z) || !st(f.out_z_batch_stride) || !st(f.out_z_d_stride)))))
         return false;
-    if (forced == 2) launch_bwd_fast<T, K, 2>(p, stream);   // uncapped registers (tuning only)
-    else             launch_bwd_fast<T, K, 4>(p, stream);   // <= 128 VGPRs: two workgroups per CU
+    // MINW = 2: registers uncapped (144-152 VGPRs, one 8-wave workgroup per CU).  The 128-VGPR build (MINW = 4, two
+    // workgroups per CU) measured ~12% faster but needs 28-48 bytes of scratch per lane, and hipcc (ROCm 7.2) may
+    // place such a VGPR spill at the top of the join block of a divergent loop, BEFORE the s_or_b64 that
+    // restores EXEC: the store then runs with EXEC = 0, nothing is saved, and the reload returns garbage (seen as
+    // wrong gradients and a GPU memory fault in fp32 once an unrelated edit changed the allocation).  No kernel
+    // of this library may use scratch: `make check-scratch` (part of the default build) enforces it.
+    launch_bwd_fast<T, K, 2>(p, stream);
     return true;
 }
 

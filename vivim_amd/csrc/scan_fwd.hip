@@ -401,7 +401,7 @@ static bool try_fwd_nsplit(const vivim_ssm_fwd_params& p, hipStream_t stream) {
     if (p.z && (!al(p.z) || !al(p.out_z) || !st(p.z_batch_stride) || !st(p.z_d_stride) ||
                 !st(p.out_z_batch_stride) || !st(p.out_z_d_stride)))
         return false;
-    static const int forced = [] { const char* e = getenv("VIVIM_FWD_VARIANT"); return e ? atoi(e) : 0; }();
+    const int forced = tuning_fwd_variant();
     // 512-token steps (K=8) halve the per-step fixed cost; 256-token steps (K=4) need 100 instead of 160 VGPRs,
     // so several workgroups share a CU -- better once there are enough workgroups to fill the chip twice.
     const int64_t nwg = (int64_t)((p.dim / p.n_groups + kNsR - 1) / kNsR) * p.n_groups * p.batch;
@@ -409,7 +409,6 @@ static bool try_fwd_nsplit(const vivim_ssm_fwd_params& p, hipStream_t stream) {
     switch (variant) {
         case 2:  launch_fwd_nsplit<T, 4, 8, 2>(p, stream); break;     // K=4
         case 3:  return false;                                         // generic kernel (tuning only)
-        case 4:  launch_fwd_nsplit<T, 8, 8, 4>(p, stream); break;     // K=8 capped at 128 VGPRs (tuning only)
         default: launch_fwd_nsplit<T, 8, 8, 2>(p, stream); break;     // K=8
     }
     return true;
@@ -439,7 +438,7 @@ static_assert(kWave * 4 == kChunk, "generic kernel step must equal the checkpoin
 bool try_fwd_chan(const vivim_ssm_fwd_params& p, hipStream_t stream);   // scan_fwd_chan.hip
 
 bool ssm_fwd_dispatch(const vivim_ssm_fwd_params& p, hipStream_t s) {
-    if (try_fwd_chan(p, s)) return true;               // lanes = channels (dstate 16, aligned, workspace given)
+    if (try_fwd_chan(p, s)) return true;               // lanes = channels: opt-in (tuning 5), dstate 16, workspace given
     switch (p.itype) {
         case VIVIM_F32: if (!try_fwd_nsplit<float>(p, s)) launch_fwd<float, 4, 2>(p, s); return true;
         case VIVIM_F16: if (!try_fwd_nsplit<f16_t>(p, s)) launch_fwd<f16_t, 4, 2>(p, s); return true;

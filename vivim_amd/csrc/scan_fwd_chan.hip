@@ -6,9 +6,13 @@
 //     lane walks its tokens serially with all N=16 states h[n] in registers: the recurrence needs no cross-lane
 //     operation, no barrier and no second "apply" sweep -- 4 VALU ops + 1 exp per state update, 16 independent
 //     dependency chains per lane;
-//   * B_n[t] and C_n[t] are the same for the 64 channels of the wave, so they are read with SCALAR loads (the
-//     pointers are cast to the constant address space: the rows are never written by this kernel) and enter
-//     the fma as SGPR operands -- no LDS traffic, no VGPRs;
+//   * B_n[t] and C_n[t] are the same for the 64 channels of the wave, so they are read with SCALAR loads and
+//     enter the fma as SGPR operands -- no LDS traffic, no VGPRs.  A small pre-kernel repacks B and C into fp32
+//     token-major rows BC[t] = {B_0..B_15, C_0..C_15} (128 bytes per token, in the workspace): one
+//     s_load_dwordx8 per operand per half token, no per-element unpacking on the scalar ALU.  Two scalar sets
+//     (states 0-7, states 8-15; 32 SGPRs in all) ping-pong half a token ahead.  Scalar loads return out of order,
+//     so every wait on them is lgkmcnt(0): each set is re-loaded right AFTER the explicit wait that precedes the
+//     other set's use, never right before one (that would expose the full scalar-load latency);
 //   * u / delta / z / out / out_z rows are token-contiguous while lanes are channels: tiles of 64 channels x TT
 //     tokens go through wave-private LDS (coalesced 16-byte global accesses on one side, conflict-free
 //     ds_read_b128 / ds_write_b128 of a lane's own row on the other; rows padded by 16 bytes);
@@ -22,61 +26,141 @@
 namespace vivim {
 
 constexpr int kChN = 16;           // states (compile time: they live in registers)
-constexpr int kChWaves = 2;        // independent waves per workgroup (15 KB of LDS each)
+constexpr int kChWaves = 2;        // independent waves per workgroup
+constexpr int kChTT = 16;          // tokens per tile (16-bit: 32-byte row pieces, 9 KB of LDS per wave; fp32: 64-byte, 15 KB)
 
 struct FwdSeg {
     int S, seg_tiles;              // segments, TT-token tiles per segment
     float* H;                      // [batch][dim][S][N]  PASS 1: end state for zero inflow; after the carry kernel: inflow
     float* dsum;                   // [batch][dim][S]     sum of softplus(delta + bias) over the segment
+    const float* BC;               // [batch][groups][Lpad + 1][32]  fp32 token-major B / C (ssm_fwd_bc_kernel)
+    int Lpad;
 };
 
-typedef const __attribute__((address_space(4))) uint32_t* cptr32;
 
-// B/C scalars of GT consecutive tokens of one state row: 8 bytes through the scalar cache.
-template <typename T> struct ScalarRow;
-template <> struct ScalarRow<float> {
-    static constexpr int GT = 2;
-    uint32_t w0, w1;
-    __device__ __forceinline__ void load(const float* row, int t) {
-        cptr32 q = (cptr32)(uintptr_t)(row + t);
-        w0 = q[0]; w1 = q[1];
+// BC[b][g][t] = [B_0..7 | C_0..7 | B_8..15 | C_8..15](t) as fp32; zero rows for L <= t <= Lpad (Lpad + 1 rows).
+template <typename T>
+__global__ void __launch_bounds__(256) ssm_fwd_bc_kernel(const vivim_ssm_fwd_params p, float* __restrict__ BC, int Lpad) {
+    __shared__ float tile[64][33];
+    const int tid = threadIdx.x;
+    const int t0 = blockIdx.x * 64, g = blockIdx.y, b = blockIdx.z;
+    const T* __restrict__ Bp = static_cast<const T*>(p.B) + b * p.B_batch_stride + g * p.B_group_stride;
+    const T* __restrict__ Cp = static_cast<const T*>(p.C) + b * p.C_batch_stride + g * p.C_group_stride;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = i * 4 + (tid >> 6), t = t0 + (tid & 63);
+        float v = 0.0f;
+        if (t < p.seqlen)
+            v = to_f32(row < 16 ? Bp[row * p.B_dstate_stride + t] : Cp[(row - 16) * p.C_dstate_stride + t]);
+        tile[tid & 63][((row & 8) << 1) | ((row >> 4) << 3) | (row & 7)] = v;   // [B0-7 | C0-7 | B8-15 | C8-15]
     }
-    __device__ __forceinline__ float get(int j) const { return __uint_as_float(j == 0 ? w0 : w1); }
-};
-template <> struct ScalarRow<bf16_t> {
-    static constexpr int GT = 4;
-    uint32_t w0, w1;
-    __device__ __forceinline__ void load(const bf16_t* row, int t) {
-        cptr32 q = (cptr32)(uintptr_t)(row + t);
-        w0 = q[0]; w1 = q[1];
+    __syncthreads();
+    float* __restrict__ dst = BC + ((int64_t)(b * p.n_groups + g) * (Lpad + 1) + t0) * 32;   // + 1: prefetch overrun row
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = i * 256 + tid;
+        if (t0 + (idx >> 5) <= Lpad) dst[idx] = tile[idx >> 5][idx & 31];
     }
-    __device__ __forceinline__ float get(int j) const {
-        const uint32_t w = j < 2 ? w0 : w1;
-        return __uint_as_float((j & 1) ? (w & 0xffff0000u) : (w << 16));
-    }
-};
-template <> struct ScalarRow<f16_t> {
-    static constexpr int GT = 4;
-    uint32_t w0, w1;
-    __device__ __forceinline__ void load(const f16_t* row, int t) {
-        cptr32 q = (cptr32)(uintptr_t)(row + t);
-        w0 = q[0]; w1 = q[1];
-    }
-    __device__ __forceinline__ float get(int j) const {
-        const uint32_t w = j < 2 ? w0 : w1;
-        const uint16_t hbits = (uint16_t)((j & 1) ? (w >> 16) : (w & 0xffffu));
-        return (float)__builtin_bit_cast(f16_t, hbits);
-    }
-};
+}
+
+// ---- the half-token state update, hand-scheduled -------------------------------------------------------------
+// 8 states of one token: a = exp2(dl*A2); h = a*h + (w*B); y += h*C  with B, C as SGPR operands.
+// Two FIXED scalar sets ping-pong: X = s[68:83], Y = s[84:99] (one BC half row each: B0-7 | C0-7).  A block
+// first issues the load of the set the NEXT block consumes, computes from its own set, and ends with
+// s_waitcnt lgkmcnt(0): nothing of ours is in flight between blocks, so the compiler's own waits never drain a
+// prefetch early.  The kernel is compiled with amdgpu_num_sgpr(kChSgprLimit): the compiler never allocates
+// s[68:99] itself, so the sets survive the compiler-generated code between the blocks (register allocation kept
+// spilling the scalar sets to VGPR lanes inside the hot loop when this was plain C++).
+#define CH_S4(i0, i1, i2, i3, B0, B1, B2, B3)                                                   \
+    "v_mul_f32 %[t0], %[dl], %[a" #i0 "]\n\tv_mul_f32 %[t1], %[dl], %[a" #i1 "]\n\t"            \
+    "v_mul_f32 %[t2], %[dl], %[a" #i2 "]\n\tv_mul_f32 %[t3], %[dl], %[a" #i3 "]\n\t"            \
+    "v_exp_f32 %[t0], %[t0]\n\tv_exp_f32 %[t1], %[t1]\n\t"                                      \
+    "v_exp_f32 %[t2], %[t2]\n\tv_exp_f32 %[t3], %[t3]\n\t"                                      \
+    "v_mul_f32 %[u0], " #B0 ", %[w]\n\tv_mul_f32 %[u1], " #B1 ", %[w]\n\t"                      \
+    "v_mul_f32 %[u2], " #B2 ", %[w]\n\tv_mul_f32 %[u3], " #B3 ", %[w]\n\t"                      \
+    "v_fma_f32 %[h" #i0 "], %[t0], %[h" #i0 "], %[u0]\n\tv_fma_f32 %[h" #i1 "], %[t1], %[h" #i1 "], %[u1]\n\t" \
+    "v_fma_f32 %[h" #i2 "], %[t2], %[h" #i2 "], %[u2]\n\tv_fma_f32 %[h" #i3 "], %[t3], %[h" #i3 "], %[u3]\n\t"
+#define CH_Y4(i0, i1, i2, i3, C0, C1, C2, C3)                                                   \
+    "v_fma_f32 %[y0], %[h" #i0 "], " #C0 ", %[y0]\n\tv_fma_f32 %[y1], %[h" #i1 "], " #C1 ", %[y1]\n\t" \
+    "v_fma_f32 %[y0], %[h" #i2 "], " #C2 ", %[y0]\n\tv_fma_f32 %[y1], %[h" #i3 "], " #C3 ", %[y1]\n\t"
+#define CH_OPERANDS(hp, ap)                                                                                    \
+    : [h0] "+v"(hp[0]), [h1] "+v"(hp[1]), [h2] "+v"(hp[2]), [h3] "+v"(hp[3]), [h4] "+v"(hp[4]), [h5] "+v"(hp[5]), \
+      [h6] "+v"(hp[6]), [h7] "+v"(hp[7]), [y0] "+v"(y0), [y1] "+v"(y1), [t0] "=&v"(t0), [t1] "=&v"(t1),          \
+      [t2] "=&v"(t2), [t3] "=&v"(t3), [u0] "=&v"(u0), [u1] "=&v"(u1), [u2] "=&v"(u2), [u3] "=&v"(u3)             \
+    : [a0] "v"(ap[0]), [a1] "v"(ap[1]), [a2] "v"(ap[2]), [a3] "v"(ap[3]), [a4] "v"(ap[4]), [a5] "v"(ap[5]),      \
+      [a6] "v"(ap[6]), [a7] "v"(ap[7]), [dl] "v"(dl), [w] "v"(w), [ptr] "s"(next)
+#define CH_CLOB_X "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83"
+#define CH_CLOB_Y "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
+
+constexpr int kChSgprLimit = 64;
+
+// cur = X: computes from s[68:83], prefetches `next` into s[84:99]
+template <int PASS>
+__device__ __forceinline__ void chan_half_x(float* hp, const float* ap, float dl, float w, float& y0, float& y1,
+                                            const float* next) {
+    float t0, t1, t2, t3, u0, u1, u2, u3;
+    if (PASS == 2)
+        asm volatile("s_load_dwordx16 s[84:99], %[ptr], 0x0\n\t"
+                     CH_S4(0, 1, 2, 3, s68, s69, s70, s71) CH_S4(4, 5, 6, 7, s72, s73, s74, s75)
+                     CH_Y4(0, 1, 2, 3, s76, s77, s78, s79) CH_Y4(4, 5, 6, 7, s80, s81, s82, s83)
+                     "s_waitcnt lgkmcnt(0)"
+                     CH_OPERANDS(hp, ap) : CH_CLOB_X, CH_CLOB_Y);
+    else
+        asm volatile("s_load_dwordx8 s[84:91], %[ptr], 0x0\n\t"
+                     CH_S4(0, 1, 2, 3, s68, s69, s70, s71) CH_S4(4, 5, 6, 7, s72, s73, s74, s75)
+                     "s_waitcnt lgkmcnt(0)"
+                     CH_OPERANDS(hp, ap) : CH_CLOB_X, CH_CLOB_Y);
+}
+// cur = Y: computes from s[84:99], prefetches `next` into s[68:83]
+template <int PASS>
+__device__ __forceinline__ void chan_half_y(float* hp, const float* ap, float dl, float w, float& y0, float& y1,
+                                            const float* next) {
+    float t0, t1, t2, t3, u0, u1, u2, u3;
+    if (PASS == 2)
+        asm volatile("s_load_dwordx16 s[68:83], %[ptr], 0x0\n\t"
+                     CH_S4(0, 1, 2, 3, s84, s85, s86, s87) CH_S4(4, 5, 6, 7, s88, s89, s90, s91)
+                     CH_Y4(0, 1, 2, 3, s92, s93, s94, s95) CH_Y4(4, 5, 6, 7, s96, s97, s98, s99)
+                     "s_waitcnt lgkmcnt(0)"
+                     CH_OPERANDS(hp, ap) : CH_CLOB_X, CH_CLOB_Y);
+    else
+        asm volatile("s_load_dwordx8 s[68:75], %[ptr], 0x0\n\t"
+                     CH_S4(0, 1, 2, 3, s84, s85, s86, s87) CH_S4(4, 5, 6, 7, s88, s89, s90, s91)
+                     "s_waitcnt lgkmcnt(0)"
+                     CH_OPERANDS(hp, ap) : CH_CLOB_X, CH_CLOB_Y);
+}
+// the first half row of a segment into X
+template <int PASS>
+__device__ __forceinline__ void chan_prime_x(const float* next) {
+    if (PASS == 2) asm volatile("s_load_dwordx16 s[68:83], %[ptr], 0x0\n\ts_waitcnt lgkmcnt(0)" : : [ptr] "s"(next) : CH_CLOB_X, CH_CLOB_Y);
+    else           asm volatile("s_load_dwordx8 s[68:75], %[ptr], 0x0\n\ts_waitcnt lgkmcnt(0)" : : [ptr] "s"(next) : CH_CLOB_X, CH_CLOB_Y);
+}
+
+typedef const __attribute__((address_space(4))) vivim_ssm_fwd_params* kparams_t;
+
+// The kernel arguments, re-read through a pointer the compiler cannot see through.  The tile I/O phases use this
+// instead of `p`: their ~40 SGPRs of pointers and strides would otherwise stay live across the compute loop and
+// push the B/C scalars out of the SGPR file (spills to VGPR lanes inside the hot loop).  `p` is argument 0.
+__device__ __forceinline__ kparams_t fresh_params() {
+    kparams_t q = (kparams_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(q));
+    return q;
+}
 
 template <typename T, int PASS, bool HAS_Z>
-__global__ void __launch_bounds__(kChWaves * kWave) ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
+__global__ void __launch_bounds__(kChWaves * kWave) __attribute__((amdgpu_num_sgpr(kChSgprLimit)))
+ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
     constexpr int N = kChN;
     constexpr int EPV = 16 / (int)sizeof(T);          // elements per 16-byte vector
-    constexpr int TT = 4 * EPV;                       // tokens per tile: 64 bytes of a row (32 for 16-bit, 16 for fp32)
-    constexpr int ROWB = 64 + 16;                     // padded LDS row, bytes
-    constexpr int GT = ScalarRow<T>::GT;
+    constexpr int TT = kChTT;                         // tokens per tile
+    constexpr int RB = TT * (int)sizeof(T);           // bytes of a row inside a tile (32 for 16-bit, 64 for fp32)
+    constexpr int LPR = RB / 16;                      // lanes (16-byte columns) per row
+    constexpr int RPI = kWave / LPR;                  // rows per cooperative load/store instruction
+    constexpr int NIO = kWave / RPI;                  // instructions per tile and stream
+    constexpr int ROWB = RB + 16;                     // padded LDS row, bytes (conflict-free 8/16-byte own-row access)
     constexpr int NARR = PASS == 2 && HAS_Z ? 3 : 2;  // resident tiles: u, delta (, z)
+    constexpr int TB = 4;                             // tokens per compute block (L % TB == 0, kChunk % TB == 0)
+    typedef uint32_t __attribute__((ext_vector_type(4))) v4;
+    typedef typename Pack<T, TB * (int)sizeof(T)>::type vblk;
     __shared__ __attribute__((aligned(16))) unsigned char lds[kChWaves * NARR * kWave * ROWB];
 
     const int tid = threadIdx.x;
@@ -84,161 +168,162 @@ __global__ void __launch_bounds__(kChWaves * kWave) ssm_fwd_chan_kernel(const vi
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y, seg = blockIdx.z;
     const int L = p.seqlen;
-    const int cpg = p.dim / p.n_groups;
-    const int bpg = (cpg + kWave - 1) / kWave;        // 64-channel blocks per B/C group
+    const int cpg = p.dim / p.n_groups;               // % 64 == 0 (host)
+    const int bpg = cpg / kWave;                      // 64-channel blocks per B/C group
     const int cb = blockIdx.x * kChWaves + wave;
     if (cb >= bpg * p.n_groups) return;               // waves are independent: no barrier below
     const int g = cb / bpg;
-    const int c0 = g * cpg + (cb - g * bpg) * kWave;
-    const int cend = (g + 1) * cpg;
-    const int d = min(c0 + lane, cend - 1);           // surplus lanes shadow the last channel, never stored
-    const bool dvalid = c0 + lane < cend;
+    const int c0 = cb * kWave;
+    const int d = c0 + lane;
 
     unsigned char* tile_u = lds + (wave * NARR + 0) * kWave * ROWB;
     unsigned char* tile_d = lds + (wave * NARR + 1) * kWave * ROWB;
     unsigned char* tile_z = lds + (wave * NARR + (NARR - 1)) * kWave * ROWB;   // only used when NARR == 3
 
-    const float* __restrict__ A = static_cast<const float*>(p.A);
     float A2[N], h[N];
+    {
+        const float* __restrict__ A = static_cast<const float*>(p.A);
 #pragma unroll
-    for (int n = 0; n < N; ++n) {
-        A2[n] = A[d * p.A_d_stride + n * p.A_dstate_stride] * kLog2e;     // fwd_kernel.cuh:168-175
-        h[n] = (PASS == 2 && seg > 0) ? sg.H[(((int64_t)b * p.dim + d) * sg.S + seg) * N + n] : 0.0f;
+        for (int n = 0; n < N; ++n) {
+            A2[n] = A[d * p.A_d_stride + n * p.A_dstate_stride] * kLog2e;     // fwd_kernel.cuh:168-175
+            h[n] = (PASS == 2 && seg > 0) ? sg.H[(((int64_t)b * p.dim + d) * sg.S + seg) * N + n] : 0.0f;
+        }
     }
     const float Dv = p.D ? static_cast<const float*>(p.D)[d] : 0.0f;
     const float bias = p.delta_bias ? static_cast<const float*>(p.delta_bias)[d] : 0.0f;
-    const T* __restrict__ Brow = static_cast<const T*>(p.B) + b * p.B_batch_stride + g * p.B_group_stride;
-    const T* __restrict__ Crow = static_cast<const T*>(p.C) + b * p.C_batch_stride + g * p.C_group_stride;
-    const int64_t sB = __builtin_amdgcn_readfirstlane((int)p.B_dstate_stride);
-    const int64_t sC = __builtin_amdgcn_readfirstlane((int)p.C_dstate_stride);
+    const bool sp_on = p.delta_softplus;
+    const float* __restrict__ bc = sg.BC + (int64_t)(b * p.n_groups + g) * (sg.Lpad + 1) * 32;
+    const int nck = (L + kChunk - 1) / kChunk;
+    float* __restrict__ xlane = static_cast<float*>(p.x) + ((int64_t)b * p.dim + d) * nck * N;   // per-lane (VGPRs)
 
     // cooperative tile I/O: instruction i moves rows i*16 + lane/4, 16-byte column lane%4
-    const int io_col = lane & 3;
-    const int io_row0 = lane >> 2;
-    const T* __restrict__ gu = static_cast<const T*>(p.u) + b * p.u_batch_stride;
-    const T* __restrict__ gd = static_cast<const T*>(p.delta) + b * p.delta_batch_stride;
-    const T* __restrict__ gz = HAS_Z ? static_cast<const T*>(p.z) + b * p.z_batch_stride : nullptr;
-    T* __restrict__ go = static_cast<T*>(p.out) + b * p.out_batch_stride;
-    T* __restrict__ goz = HAS_Z ? static_cast<T*>(p.out_z) + b * p.out_z_batch_stride : nullptr;
-    float* __restrict__ xck = static_cast<float*>(p.x);
-    const int nck = (L + kChunk - 1) / kChunk;
-
+    const int io_col = lane % LPR;
+    const int io_row0 = lane / LPR;
     const int ntiles = (L + TT - 1) / TT;
     const int tile_lo = seg * sg.seg_tiles, tile_hi = min(ntiles, tile_lo + sg.seg_tiles);
     float dsum = 0.0f;
 
+    float l2_touch = 0.0f;
+    // one BC row is [B0-7 | C0-7 | B8-15 | C8-15]: a half token = 16 consecutive floats (t <= Lpad: Lpad + 1 rows)
+    // the segment's first tile is touched here (vector load, L2 allocate) so that its scalar loads do not go to HBM
+    if (lane < TT * 2) l2_touch = bc[(int64_t)min(tile_lo * TT + (lane >> 1), sg.Lpad) * 32 + (lane & 1) * 16];
+    asm volatile("s_waitcnt vmcnt(0)" : : "v"(l2_touch));
+    chan_prime_x<PASS>(bc + (int64_t)tile_lo * TT * 32);
+
+#pragma unroll 1
     for (int tile = tile_lo; tile < tile_hi; ++tile) {
-        const int t0 = tile * TT;
+        const int t0 = __builtin_amdgcn_readfirstlane(tile * TT);
         // ---- global -> LDS (coalesced 64-byte row segments) ----
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = i * 16 + io_row0;
-            const int ch = min(c0 + row, cend - 1);
+        {
+            kparams_t q = fresh_params();
             const int t = t0 + io_col * EPV;
             const bool ok = t < L;                    // L % EPV == 0 (host): a 16-byte column is all-in or all-out
-            typedef uint32_t __attribute__((ext_vector_type(4))) v4;
-            union { RawK<T, EPV> r; v4 v; } cu, cd, cz;
-            cu.r = load_vec<T, EPV>(gu + ch * p.u_d_stride + t, ok);
-            cd.r = load_vec<T, EPV>(gd + ch * p.delta_d_stride + t, ok);
-            *reinterpret_cast<v4*>(tile_u + row * ROWB + io_col * 16) = cu.v;
-            *reinterpret_cast<v4*>(tile_d + row * ROWB + io_col * 16) = cd.v;
+            const int64_t su = q->u_d_stride, sd = q->delta_d_stride;
+            const T* gu = static_cast<const T*>(q->u) + b * q->u_batch_stride + (c0 + io_row0) * su + t;
+            const T* gd = static_cast<const T*>(q->delta) + b * q->delta_batch_stride + (c0 + io_row0) * sd + t;
+            union { RawK<T, EPV> r; v4 v; } cu[NIO], cd[NIO], cz[NIO];
+            // one vector load touches the 64-byte lines of the NEXT tile's BC rows: they are in this XCD's L2 by
+            // the time the scalar loads want them (first touch would otherwise come from beyond the L2)
+            if (lane < TT * 2) l2_touch = bc[(int64_t)min(t0 + TT + (lane >> 1), sg.Lpad) * 32 + (lane & 1) * 16];
+#pragma unroll
+            for (int i = 0; i < NIO; ++i) {
+                cu[i].r = load_vec<T, EPV>(gu + i * RPI * su, ok);
+                cd[i].r = load_vec<T, EPV>(gd + i * RPI * sd, ok);
+            }
             if (NARR == 3) {
-                cz.r = load_vec<T, EPV>(gz + ch * p.z_d_stride + t, ok);
-                *reinterpret_cast<v4*>(tile_z + row * ROWB + io_col * 16) = cz.v;
+                const int64_t sz = q->z_d_stride;
+                const T* gz = static_cast<const T*>(q->z) + b * q->z_batch_stride + (c0 + io_row0) * sz + t;
+#pragma unroll
+                for (int i = 0; i < NIO; ++i) cz[i].r = load_vec<T, EPV>(gz + i * RPI * sz, ok);
+            }
+#pragma unroll
+            for (int i = 0; i < NIO; ++i) {
+                const int off = (i * RPI + io_row0) * ROWB + io_col * 16;
+                *reinterpret_cast<v4*>(tile_u + off) = cu[i].v;
+                *reinterpret_cast<v4*>(tile_d + off) = cd[i].v;
+                if (NARR == 3) *reinterpret_cast<v4*>(tile_z + off) = cz[i].v;
             }
         }
+        asm volatile("" : : "v"(l2_touch));          // the touch load must not be optimised away
         wave_lds_fence();
-        // ---- the lane's own row: TT tokens in blocks of EPV ----
+        // ---- the lane's own row: TT tokens in blocks of TB (one 8- or 16-byte LDS access per stream) ----
 #pragma unroll 1
-        for (int blk = 0; blk < 4; ++blk) {
-            const int tb = t0 + blk * EPV;
-            float uf[EPV], df[EPV], zf[EPV], yo[EPV], yz[EPV];
+        for (int blk = 0; blk < TT / TB; ++blk) {
+            const int tb = __builtin_amdgcn_readfirstlane(t0 + blk * TB);
+            if (tb >= L) break;                          // blocks never straddle L: nothing to mask below
+            float uf[TB], df[TB], zf[TB], yo[TB], dl[TB], w[TB];
             {
-                typedef uint32_t __attribute__((ext_vector_type(4))) v4;
-                union { RawK<T, EPV> r; v4 v; } cu, cd, cz;
-                cu.v = *reinterpret_cast<const v4*>(tile_u + lane * ROWB + blk * 16);
-                cd.v = *reinterpret_cast<const v4*>(tile_d + lane * ROWB + blk * 16);
+                union { RawK<T, TB> r; vblk v; } cu, cd, cz;
+                cu.v = *reinterpret_cast<const vblk*>(tile_u + lane * ROWB + blk * TB * (int)sizeof(T));
+                cd.v = *reinterpret_cast<const vblk*>(tile_d + lane * ROWB + blk * TB * (int)sizeof(T));
                 unpack(cu.r, uf);
                 unpack(cd.r, df);
                 if (NARR == 3) {
-                    cz.v = *reinterpret_cast<const v4*>(tile_z + lane * ROWB + blk * 16);
+                    cz.v = *reinterpret_cast<const vblk*>(tile_z + lane * ROWB + blk * TB * (int)sizeof(T));
                     unpack(cz.r, zf);
                 }
             }
 #pragma unroll
-            for (int q = 0; q < EPV / GT; ++q) {       // groups of GT tokens share one set of scalar B/C loads
-                const int tq = __builtin_amdgcn_readfirstlane(tb + q * GT);
-                const int ts = min(tq, L - GT);        // past the end: any valid address; those tokens are identity maps
-                ScalarRow<T> Bs[N], Cs[N];
-#pragma unroll
-                for (int n = 0; n < N; ++n) {
-                    Bs[n].load(Brow + n * sB, ts);
-                    if (PASS == 2) Cs[n].load(Crow + n * sC, ts);
-                }
-#pragma unroll
-                for (int j = 0; j < GT; ++j) {
-                    const int k = q * GT + j;
-                    const bool in = tq + j < L;
-                    const float raw = df[k] + bias;
-                    const float sp = p.delta_softplus ? softplus_ref(raw) : raw;
-                    const float dl = in ? sp : 0.0f;   // padded token: exp2(0) = 1, drive 0
-                    const float w = dl * uf[k];
-                    dsum += dl;
-                    float y = Dv * uf[k];
-#pragma unroll
-                    for (int n = 0; n < N; ++n) {
-                        const float a = fast_exp2(dl * A2[n]);
-                        h[n] = fmaf(a, h[n], w * Bs[n].get(j));
-                        if (PASS == 2) y = fmaf(h[n], Cs[n].get(j), y);
-                    }
-                    if (PASS == 2) {
-                        yo[k] = y;
-                        if (HAS_Z) yz[k] = y * zf[k] * sigmoidf_fast(zf[k]);        // fwd_kernel.cuh:290
-                        const int tk = tq + j;
-                        if (((tk + 1) & (kChunk - 1)) == 0 || tk == L - 1) {        // state after every kChunk tokens
-                            const int row = tk / kChunk;
-                            if (dvalid && row < nck) {
-                                float* xr = xck + (((int64_t)b * p.dim + d) * nck + row) * N;
-#pragma unroll
-                                for (int n = 0; n < N; ++n) xr[n] = h[n];
-                            }
-                        }
-                    }
-                }
+            for (int k = 0; k < TB; ++k) {
+                const float raw = df[k] + bias;
+                dl[k] = sp_on ? softplus_ref(raw) : raw;
+                w[k] = dl[k] * uf[k];
+                dsum += dl[k];
+                yo[k] = Dv * uf[k];
             }
-            if (PASS == 2) {                           // results overwrite the lane's own consumed input columns
-                typedef uint32_t __attribute__((ext_vector_type(4))) v4;
-                union { T e[EPV]; v4 v; } co, cz;
+            const float* bct = bc + (int64_t)tb * 32;     // uniform: this block's first BC row
 #pragma unroll
-                for (int k = 0; k < EPV; ++k) co.e[k] = from_f32<T>(yo[k]);
-                *reinterpret_cast<v4*>(tile_u + lane * ROWB + blk * 16) = co.v;
+            for (int k = 0; k < TB; ++k) {
+                float y1 = 0.0f;
+                chan_half_x<PASS>(h, A2, dl[k], w[k], yo[k], y1, bct + k * 32 + 16);          // prefetch: own high half
+                chan_half_y<PASS>(h + 8, A2 + 8, dl[k], w[k], yo[k], y1, bct + (k + 1) * 32); // prefetch: next token
+                if (PASS == 2) yo[k] += y1;
+            }
+            if (PASS == 2) {
+                // state after every kChunk tokens and after the last one: always the last token of a block
+                const int tl = tb + TB - 1;
+                if (((tl + 1) & (kChunk - 1)) == 0 || tl == L - 1) {
+                    float* xr = xlane + (tl / kChunk) * N;
+#pragma unroll
+                    for (int n = 0; n < N; ++n) xr[n] = h[n];
+                }
+                // results overwrite the lane's own consumed input columns
+                union { T e[TB]; vblk v; } co, cz;
+#pragma unroll
+                for (int k = 0; k < TB; ++k) co.e[k] = from_f32<T>(yo[k]);
+                *reinterpret_cast<vblk*>(tile_u + lane * ROWB + blk * TB * (int)sizeof(T)) = co.v;
                 if (HAS_Z) {
 #pragma unroll
-                    for (int k = 0; k < EPV; ++k) cz.e[k] = from_f32<T>(yz[k]);
-                    *reinterpret_cast<v4*>(tile_z + lane * ROWB + blk * 16) = cz.v;
+                    for (int k = 0; k < TB; ++k)
+                        cz.e[k] = from_f32<T>(yo[k] * zf[k] * sigmoidf_fast(zf[k]));            // fwd_kernel.cuh:290
+                    *reinterpret_cast<vblk*>(tile_z + lane * ROWB + blk * TB * (int)sizeof(T)) = cz.v;
                 }
             }
         }
         wave_lds_fence();
         if (PASS == 2) {                               // LDS -> global, coalesced
+            kparams_t q = fresh_params();
+            const int t = t0 + io_col * EPV;
+            if (t < L) {
+                const int64_t so = q->out_d_stride;
+                T* go = static_cast<T*>(q->out) + b * q->out_batch_stride + (c0 + io_row0) * so + t;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = i * 16 + io_row0;
-                const int ch = c0 + row;
-                const int t = t0 + io_col * EPV;
-                if (ch < cend && t < L) {
-                    typedef uint32_t __attribute__((ext_vector_type(4))) v4;
-                    *reinterpret_cast<v4*>(go + ch * p.out_d_stride + t) =
-                        *reinterpret_cast<const v4*>(tile_u + row * ROWB + io_col * 16);
-                    if (HAS_Z)
-                        *reinterpret_cast<v4*>(goz + ch * p.out_z_d_stride + t) =
-                            *reinterpret_cast<const v4*>(tile_z + row * ROWB + io_col * 16);
+                for (int i = 0; i < NIO; ++i)
+                    *reinterpret_cast<v4*>(go + i * RPI * so) =
+                        *reinterpret_cast<const v4*>(tile_u + (i * RPI + io_row0) * ROWB + io_col * 16);
+                if (HAS_Z) {
+                    const int64_t soz = q->out_z_d_stride;
+                    T* goz = static_cast<T*>(q->out_z) + b * q->out_z_batch_stride + (c0 + io_row0) * soz + t;
+#pragma unroll
+                    for (int i = 0; i < NIO; ++i)
+                        *reinterpret_cast<v4*>(goz + i * RPI * soz) =
+                            *reinterpret_cast<const v4*>(tile_z + (i * RPI + io_row0) * ROWB + io_col * 16);
                 }
             }
             wave_lds_fence();
         }
     }
-    if (PASS == 1 && dvalid) {
+    if (PASS == 1) {
         float* Hs = sg.H + (((int64_t)b * p.dim + d) * sg.S + seg) * N;
 #pragma unroll
         for (int n = 0; n < N; ++n) Hs[n] = h[n];
@@ -247,20 +332,50 @@ __global__ void __launch_bounds__(kChWaves * kWave) ssm_fwd_chan_kernel(const vi
 }
 
 // In place: H[s] (end state of segment s for zero inflow) becomes the state flowing INTO segment s.
-__global__ void ssm_fwd_carry_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
+// One wave (= one workgroup) per (batch, channel).  The whole chain (S x 16 states + S delta sums) is first pulled
+// into LDS with coalesced loads that are all in flight together; the serial part then runs out of LDS:
+// lane = (segment j of a group of 4, state n), the 4 affine maps x -> P x + H of a group are composed with two
+// shuffle steps, the carry of the previous group comes from lanes 48..63, the next group's LDS reads are issued
+// before the current group is processed.  (The first version walked global memory directly: one memory latency per
+// segment, 90 us for S = 342 -- more than the two scan passes together.)
+__global__ void __launch_bounds__(kWave) ssm_fwd_carry_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
     constexpr int N = kChN;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)p.batch * p.dim * N) return;
-    const int n = (int)(i % N);
-    const int64_t bd = i / N;
+    extern __shared__ __attribute__((aligned(16))) float cs[];
+    const int lane = threadIdx.x;
+    const int64_t bd = blockIdx.x;
+    const int S = sg.S;
+    float* Hs = cs;                                     // [S][N]
+    float* ds = cs + S * N;                             // [S]
+    float* __restrict__ Hrow = sg.H + bd * S * N;
+    const float* __restrict__ drow = sg.dsum + bd * S;
+    for (int i = lane * 4; i < S * N; i += kWave * 4)   // S * N % 4 == 0, rows are 64-byte aligned
+        *reinterpret_cast<float4*>(Hs + i) = *reinterpret_cast<const float4*>(Hrow + i);
+    for (int i = lane; i < S; i += kWave) ds[i] = drow[i];
+    __syncthreads();
+    const int n = lane & 15, j = lane >> 4;
     const int dch = (int)(bd % p.dim);
     const float A2 = static_cast<const float*>(p.A)[dch * p.A_d_stride + n * p.A_dstate_stride] * kLog2e;
-    float hin = 0.0f;
-    for (int s = 0; s < sg.S; ++s) {
-        const int64_t k = (bd * sg.S + s) * N + n;
-        const float Hs = sg.H[k];
-        sg.H[k] = hin;
-        hin = fmaf(fast_exp2(A2 * sg.dsum[bd * sg.S + s]), hin, Hs);
+    float carry = 0.0f;                                 // state flowing into the current group (per n, replicated over j)
+    float Hn = j < S ? Hs[j * N + n] : 0.0f;
+    float dn = j < S ? ds[j] : 0.0f;
+    for (int s0 = 0; s0 < S; s0 += 4) {
+        const float Hc = Hn, dc = dn;
+        const int sn = s0 + 4 + j;
+        Hn = sn < S ? Hs[sn * N + n] : 0.0f;            // next group
+        dn = sn < S ? ds[sn] : 0.0f;
+        // inclusive scan over j of the maps (P, H); segments past S are identity maps (P = 1, H = 0)
+        float P = s0 + j < S ? fast_exp2(A2 * dc) : 1.0f, H = Hc;
+        float Pp = __shfl_up(P, 16, kWave), Hp = __shfl_up(H, 16, kWave);
+        if (j >= 1) { H = fmaf(P, Hp, H); P *= Pp; }
+        Pp = __shfl_up(P, 32, kWave); Hp = __shfl_up(H, 32, kWave);
+        if (j >= 2) { H = fmaf(P, Hp, H); P *= Pp; }
+        // exclusive form: the inflow of segment s0 + j is the inclusive result of j - 1 applied to the carry
+        float Pe = __shfl_up(P, 16, kWave), He = __shfl_up(H, 16, kWave);
+        if (j == 0) { Pe = 1.0f; He = 0.0f; }
+        const float hin = fmaf(Pe, carry, He);
+        if (s0 + j < S) Hrow[(s0 + j) * N + n] = hin;
+        const float cnext = fmaf(P, carry, H);          // valid in j == 3: state after the whole group
+        carry = __shfl(cnext, 48 + n, kWave);
     }
 }
 
@@ -270,7 +385,7 @@ static void fwd_chan_segmentation(const vivim_ssm_fwd_params& f, int tt, int& S,
     const int64_t waves = (int64_t)((cpg + kWave - 1) / kWave) * f.n_groups * f.batch;
     int64_t want = (2048 + waves - 1) / waves;
     if (want > ntiles) want = ntiles;
-    if (want > 1024) want = 1024;
+    if (want > 512) want = 512;       // the carry kernel keeps a whole chain in LDS: 512 * 17 * 4 = 34 KB
     if (want < 1) want = 1;
     seg_tiles = (int)((ntiles + want - 1) / want);
     S = (ntiles + seg_tiles - 1) / seg_tiles;
@@ -279,16 +394,14 @@ static void fwd_chan_segmentation(const vivim_ssm_fwd_params& f, int tt, int& S,
 // shape_only: pointers are not inspected (the workspace query may come before they are final)
 static bool fwd_chan_eligible(const vivim_ssm_fwd_params& p, bool shape_only = false) {
     if (!p.is_variable_B || !p.is_variable_C || p.dstate != kChN || p.seqlen % 8 != 0) return false;
-    if (p.B_dstate_stride > 0x7fffffff || p.C_dstate_stride > 0x7fffffff) return false;
-    static const int forced = [] { const char* e = getenv("VIVIM_FWD_VARIANT"); return e ? atoi(e) : 0; }();
-    if (forced != 0 && forced != 5) return false;      // tuning: another forward kernel was requested
+    if (p.dim % p.n_groups != 0 || (p.dim / p.n_groups) % kWave != 0) return false;   // whole 64-channel blocks per group
+    if (tuning_fwd_variant() != 5) return false;       // opt-in: the n-split kernel is faster at Vivim's sizes
     const int64_t epv = p.itype == VIVIM_F32 ? 4 : 8;
     auto al = [&](const void* q) { return shape_only || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     auto st = [&](int64_t e) { return e % epv == 0; };
-    if (!al(p.u) || !al(p.delta) || !al(p.B) || !al(p.C) || !al(p.out) ||
+    if (!al(p.u) || !al(p.delta) || !al(p.out) ||
         !st(p.u_batch_stride) || !st(p.u_d_stride) || !st(p.delta_batch_stride) || !st(p.delta_d_stride) ||
-        !st(p.out_batch_stride) || !st(p.out_d_stride) || !st(p.B_batch_stride) || !st(p.B_group_stride) ||
-        !st(p.B_dstate_stride) || !st(p.C_batch_stride) || !st(p.C_group_stride) || !st(p.C_dstate_stride))
+        !st(p.out_batch_stride) || !st(p.out_d_stride))
         return false;
     if (p.z && (!al(p.z) || !al(p.out_z) || !st(p.z_batch_stride) || !st(p.z_d_stride) ||
                 !st(p.out_z_batch_stride) || !st(p.out_z_d_stride)))
@@ -296,35 +409,43 @@ static bool fwd_chan_eligible(const vivim_ssm_fwd_params& p, bool shape_only = f
     return true;
 }
 
+static size_t fwd_chan_layout(const vivim_ssm_fwd_params& f, int tt, int& S, int& seg_tiles, int& Lpad,
+                              size_t& bc_floats) {
+    fwd_chan_segmentation(f, tt, S, seg_tiles);
+    Lpad = (f.seqlen + tt - 1) / tt * tt;
+    bc_floats = (size_t)f.batch * f.n_groups * (Lpad + 1) * 32;
+    const size_t h_floats = S > 1 ? (size_t)f.batch * f.dim * S * (kChN + 1) : 0;
+    return (bc_floats + h_floats) * sizeof(float);
+}
+
 size_t scan_fwd_workspace_bytes(const vivim_ssm_fwd_params& f) {
     if (!fwd_chan_eligible(f, true)) return 0;
-    int S, seg_tiles;
-    fwd_chan_segmentation(f, f.itype == VIVIM_F32 ? 16 : 32, S, seg_tiles);
-    if (S <= 1) return 16;   // still selects the channel kernel (non-zero), nothing is stored
-    return (size_t)f.batch * f.dim * S * (kChN + 1) * sizeof(float);
+    int S, seg_tiles, Lpad;
+    size_t bc;
+    return fwd_chan_layout(f, kChTT, S, seg_tiles, Lpad, bc);
 }
 
 template <typename T>
 static bool launch_fwd_chan(const vivim_ssm_fwd_params& p, hipStream_t stream) {
-    constexpr int TT = 4 * (16 / (int)sizeof(T));
-    FwdSeg sg = {1, (p.seqlen + TT - 1) / TT, nullptr, nullptr};
-    int S, seg_tiles;
-    fwd_chan_segmentation(p, TT, S, seg_tiles);
-    const size_t need = (size_t)p.batch * p.dim * S * (kChN + 1) * sizeof(float);
+    constexpr int TT = kChTT;
+    int S, seg_tiles, Lpad;
+    size_t bc_floats;
+    const size_t need = fwd_chan_layout(p, TT, S, seg_tiles, Lpad, bc_floats);
+    if (!p.workspace || (size_t)p.workspace_bytes < need || (reinterpret_cast<uintptr_t>(p.workspace) & 63)) return false;
+    FwdSeg sg = {S, seg_tiles, nullptr, nullptr, static_cast<const float*>(p.workspace), Lpad};
     if (S > 1) {
-        if (!p.workspace || (size_t)p.workspace_bytes < need) return false;
-        sg.S = S;
-        sg.seg_tiles = seg_tiles;
-        sg.H = static_cast<float*>(p.workspace);
+        sg.H = static_cast<float*>(p.workspace) + bc_floats;
         sg.dsum = sg.H + (size_t)p.batch * p.dim * S * kChN;
     }
+    hipLaunchKernelGGL((ssm_fwd_bc_kernel<T>), dim3((Lpad + 1 + 63) / 64, p.n_groups, p.batch), dim3(256), 0, stream, p,
+                       static_cast<float*>(p.workspace), Lpad);
     const int cpg = p.dim / p.n_groups;
-    const int blocks = (((cpg + kWave - 1) / kWave) * p.n_groups + kChWaves - 1) / kChWaves;
+    const int blocks = ((cpg / kWave) * p.n_groups + kChWaves - 1) / kChWaves;
     const dim3 block(kChWaves * kWave);
     if (sg.S > 1) {
         hipLaunchKernelGGL((ssm_fwd_chan_kernel<T, 1, false>), dim3(blocks, p.batch, sg.S), block, 0, stream, p, sg);
-        const int64_t nthr = (int64_t)p.batch * p.dim * kChN;
-        hipLaunchKernelGGL(ssm_fwd_carry_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream, p, sg);
+        const size_t carry_lds = (size_t)sg.S * (kChN + 1) * sizeof(float);      // <= 34 KB (S <= 512)
+        hipLaunchKernelGGL(ssm_fwd_carry_kernel, dim3((unsigned)(p.batch * p.dim)), dim3(kWave), carry_lds, stream, p, sg);
     }
     if (p.z) hipLaunchKernelGGL((ssm_fwd_chan_kernel<T, 2, true>), dim3(blocks, p.batch, sg.S), block, 0, stream, p, sg);
     else     hipLaunchKernelGGL((ssm_fwd_chan_kernel<T, 2, false>), dim3(blocks, p.batch, sg.S), block, 0, stream, p, sg);

@@ -30,7 +30,7 @@ def _taps(weight):
 def _run_fwd(x, wt, bias, dims, flip):
     B, L, C = x.shape
     D, H, W = dims
-    y = torch.empty((B, L, C), device=x.device, dtype=x.dtype)
+    y = _lib.empty((B, L, C), x.dtype, x.device)
     P = _lib.DwConvParams()
     P.batch, P.depth, P.height, P.width, P.channels = B, D, H, W, C
     P.kd, P.itype, P.flip = wt.shape[0] // 9, _DT[x.dtype], int(flip)

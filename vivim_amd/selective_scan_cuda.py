@@ -92,10 +92,10 @@ def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus):
     """-> [out, x] (+ [out_z] when z is given); selective_scan.cpp:226-336."""
     dims = _common_checks(u, delta, A, B, C, D_, z_, delta_bias_)
     batch, dim, seqlen, dstate = dims[:4]
-    out = torch.empty_like(delta)                    # inherits delta's (L, B*L, 1) strides, selective_scan.cpp:311
-    out_z = torch.empty_like(z_) if z_ is not None else None
+    out = _lib.empty_like(delta)                    # inherits delta's (L, B*L, 1) strides, selective_scan.cpp:311
+    out_z = _lib.empty_like(z_) if z_ is not None else None
     ck = chunk_len(u.dtype)
-    x = torch.empty(batch, dim, (seqlen + ck - 1) // ck, dstate, device=u.device, dtype=torch.float32)
+    x = _lib.empty((batch, dim, (seqlen + ck - 1) // ck, dstate), torch.float32, u.device)
     P = _lib.SsmFwdParams()
     _fill_fwd(P, u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, dims)
     P.out, P.x = out.data_ptr(), x.data_ptr()
@@ -105,7 +105,7 @@ def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus):
         P.out_z_batch_stride, P.out_z_d_stride = out_z.stride(0), out_z.stride(1)
     ws_bytes = _lib.lib().vivim_scan_fwd_workspace_bytes(P)
     if ws_bytes:
-        workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=u.device)
+        workspace = _lib.empty((ws_bytes,), torch.uint8, u.device)
         P.workspace, P.workspace_bytes = workspace.data_ptr(), ws_bytes
     with torch.cuda.device(u.device):
         _lib.call("vivim_selective_scan_fwd", P, torch.cuda.current_stream().cuda_stream)
@@ -139,11 +139,11 @@ def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softp
                    and tuple(dz_.shape) == (batch, dim, seqlen), "dz must match u (dtype, shape, stride(-1) == 1)")
             dz = dz_
         else:
-            dz = torch.empty_like(z_)
+            dz = _lib.empty_like(z_)
         if recompute_out_z:
-            out_z = torch.empty_like(out_)
-    du = torch.empty_like(u)
-    ddelta = torch.empty_like(delta)
+            out_z = _lib.empty_like(out_)
+    du = _lib.empty_like(u)
+    ddelta = _lib.empty_like(delta)
     # fp32 accumulators (selective_scan.cpp:458-466) carved out of ONE zero-filled buffer: one memset
     # instead of five, and dB|dC are adjacent so their cast to the input dtype is one kernel too.
     nB, nC, nA = B.numel(), C.numel(), A.numel()
@@ -181,7 +181,7 @@ def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softp
     P.dD, P.ddelta_bias = _ptr(dD), _ptr(ddelta_bias)
     ws_bytes = _lib.lib().vivim_scan_bwd_workspace_bytes(P.f)
     if ws_bytes:
-        workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=u.device)   # torch caching allocator: no sync
+        workspace = _lib.empty((ws_bytes,), torch.uint8, u.device)   # torch caching allocator: no sync
         P.workspace, P.workspace_bytes = workspace.data_ptr(), ws_bytes
     with torch.cuda.device(u.device):
         _lib.call("vivim_selective_scan_bwd", P, torch.cuda.current_stream().cuda_stream)

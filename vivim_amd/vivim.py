@@ -20,6 +20,8 @@ Differences from the reference, all additive:
 """
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -250,19 +252,6 @@ def segformer_b3_random(num_labels=150):
     return SegformerForSemanticSegmentation(segformer_b3_config(num_labels))
 
 
-def _conv1x1(conv, x):
-    """A 1x1 stride-1 nn.Conv2d evaluated as one batched GEMM on the NCHW tensor, W(Cout, Cin) @ x(B, Cin, H*W):
-    identical math, but it stays on rocBLAS/hipBLASLt instead of MIOpen (which, without a tuned find-db entry,
-    can fall back to its naive direct convolution: 87 ms for the 3072 -> 768 fuse, profiles/r01_v2_*)."""
-    if conv.kernel_size != (1, 1) or conv.stride != (1, 1) or conv.padding != (0, 0) or conv.groups != 1:
-        return conv(x)
-    b, _, h, w = x.shape
-    y = torch.matmul(conv.weight.view(conv.out_channels, conv.in_channels).to(x.dtype), x.flatten(2))
-    if conv.bias is not None:
-        y = y + conv.bias.to(y.dtype)[None, :, None]
-    return y.view(b, conv.out_channels, h, w)
-
-
 class Vivim(nn.Module):
     """modeling/vivim.py:234-348.  forward(x_in[B, nf, 3, H, W]) -> logits[B*nf, out_chans, H, W]
     (+ edge map when with_edge)."""
@@ -307,11 +296,16 @@ class Vivim(nn.Module):
             if torch.rand(1).item() > 0.5:          # per-map dropout coin flip on the CPU RNG (vivim.py:310-312)
                 state = F.dropout(state, p=self.dropout_rate / 2, training=self.training)
             feats += (state,)
-        hidden = _conv1x1(self.decoder.linear_fuse, torch.cat(feats[::-1], dim=1))
+        # linear_fuse / out stay nn.Conv2d on MIOpen, as in the reference.  They were batched GEMMs for a while (+18%
+        # frames/s): the library GEMM for 768 x 3072 x 61440 bf16 on the channels-last concat (hipBLASLt picks
+        # Custom_Cijk_Alik_Bljk_BBS_BH_Bias_HA_S_SAV_NTD_SK3_UserArgs_MT256x256x64) dies with a GPU memory access fault
+        # in no_grad forwards and, with other allocation sizes, in training; no BLAS backend / workspace setting
+        # avoided it.
+        hidden = self.decoder.linear_fuse(torch.cat(feats[::-1], dim=1))
         hidden = self.decoder.activation(self.decoder.batch_norm(hidden))
         hidden = self.decoder.dropout(self.decoder.dropout(hidden))   # applied twice (vivim.py:319-322)
         hidden = self.feature_dropout(hidden)
-        return _conv1x1(self.out, hidden)
+        return self.out(hidden)
 
     def forward(self, x_in):
         bz, nf, nc, h, w = x_in.shape
