@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define VIVIM_ABI_VERSION 3
+#define VIVIM_ABI_VERSION 4
 
 typedef enum { VIVIM_F32 = 0, VIVIM_F16 = 1, VIVIM_BF16 = 2 } vivim_dtype_t;
 
@@ -165,11 +165,31 @@ typedef struct {
     void *dbias;                /* (channels) f32 pre-zeroed, or NULL */
 } vivim_dwconv_wgrad_params;
 
+/* The three scan directions of the v3 block (mamba_simple.py:220-262) as index maps over the token axis of a
+ * frame-major clip, l = t*hw + p with t < nframes, p < hw = seqlen / nframes:
+ *   direction 0: l            (forward in time)
+ *   direction 1: seqlen-1-l   (xz.flip(-1), :231 / out_b.flip(-1), :264)
+ *   direction 2: p*nframes+t  (chunk(nframes) + stack(-1) + flatten, :245-247; inverse at :261)
+ * scatter: dst[b][c / csplit][g][c % csplit][m_g(l)] = scale * src[b][c][l]   for g = 0, 1, 2    (one read, three writes)
+ * gather : dst[b][c][l] = scale * sum_g src[b][c / csplit][g][c % csplit][m_g(l)]               (three reads, one write)
+ * They replace flip + stack/permute copies and the out + out_b + out_s sum, and are each other's gradient. */
+typedef struct {
+    int32_t batch, channels, seqlen, nframes;
+    int32_t csplit;              /* channels per half: the stacked tensor is (batch, channels/csplit, 3, csplit, seqlen) */
+    int32_t itype;               /* VIVIM_F32 / F16 / BF16 */
+    float scale;
+    int32_t _pad0;
+    int64_t flat_batch_stride, flat_c_stride;                  /* the (batch, channels, seqlen) side; unit seqlen stride */
+    int64_t stk_batch_stride, stk_half_stride, stk_dir_stride, stk_c_stride;   /* the stacked side; unit seqlen stride */
+    const void *src;
+    void *dst;
+} vivim_dir_params;
+
 int vivim_abi_version(void);
 const char *vivim_last_error(void);
 
 /* sizeof() of a params struct as this library was compiled, so a foreign-language binding can assert
- * its own layout: which = 0 ssm_fwd, 1 ssm_bwd, 2 conv_fwd, 3 conv_bwd, 4 dwconv, 5 dwconv_wgrad; 0 for anything else. */
+ * its own layout: which = 0 ssm_fwd, 1 ssm_bwd, 2 conv_fwd, 3 conv_bwd, 4 dwconv, 5 dwconv_wgrad, 6 dir; 0 for anything else. */
 size_t vivim_sizeof(int which);
 
 /* Tokens per checkpoint row of `x` for an input dtype; n_chunks = ceil(seqlen / chunk_len). */
@@ -194,6 +214,8 @@ int vivim_causal_conv1d_fwd(const vivim_conv_fwd_params *p, void *stream);
 int vivim_causal_conv1d_bwd(const vivim_conv_bwd_params *p, void *stream);
 int vivim_dwconv_fwd(const vivim_dwconv_params *p, void *stream);            /* also the input gradient (flip = 1) */
 int vivim_dwconv_wgrad(const vivim_dwconv_wgrad_params *p, void *stream);
+int vivim_dir_scatter(const vivim_dir_params *p, void *stream);
+int vivim_dir_gather(const vivim_dir_params *p, void *stream);
 
 #ifdef __cplusplus
 }

@@ -27,10 +27,10 @@ def test_header_symbols_exported():
 def test_struct_layouts_match():
     L = _lib.lib()
     for which, st in enumerate((_lib.SsmFwdParams, _lib.SsmBwdParams, _lib.ConvFwdParams, _lib.ConvBwdParams,
-                                _lib.DwConvParams, _lib.DwConvWgradParams)):
+                                _lib.DwConvParams, _lib.DwConvWgradParams, _lib.DirParams)):
         assert L.vivim_sizeof(which) == ctypes.sizeof(st)
     assert L.vivim_sizeof(99) == 0
-    assert L.vivim_abi_version() == 3
+    assert L.vivim_abi_version() == 4
     assert L.vivim_scan_chunk_len(_lib.F32) > 0 and L.vivim_scan_chunk_len(_lib.BF16) % 64 == 0
 
 
@@ -91,3 +91,19 @@ def test_tuning_roundtrip():
     assert prev >= 0
     assert L.vivim_set_tuning(0, prev) == 5
     assert L.vivim_set_tuning(2, 0) == -1 and L.vivim_set_tuning(0, -3) == -1
+
+
+def test_dir_maps_reject_bad_arguments_on_host():
+    """vivim_dir_scatter / vivim_dir_gather validate before launching (no GPU needed for the rejections)."""
+    import ctypes
+    L = _lib.lib()
+    P = _lib.DirParams()
+    P.batch, P.channels, P.seqlen, P.nframes, P.csplit, P.itype, P.scale = 1, 4, 30, 5, 2, _lib.BF16, 1.0
+    P.src = P.dst = 0
+    for fn in (L.vivim_dir_scatter, L.vivim_dir_gather):
+        assert fn(ctypes.byref(P), None) != 0                      # null pointers
+    P.src = P.dst = 4096
+    assert L.vivim_dir_scatter(ctypes.byref(P), None) != 0        # 30 bf16 tokens are not whole 16-byte vectors
+    P.seqlen, P.nframes = 32, 5
+    assert L.vivim_dir_scatter(ctypes.byref(P), None) != 0        # seqlen not a multiple of nframes
+    assert b"" != L.vivim_last_error()

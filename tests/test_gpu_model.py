@@ -105,3 +105,61 @@ def test_vivim_inference_matches_training_graph(cuda):
     torch.cuda.synchronize()
     assert a.shape == (15, 3, 256, 256) and torch.isfinite(a).all()
     assert (a.float() - b.float()).abs().max() <= 2e-2 * b.float().abs().max()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_grouped_directions_match_separate_calls(dtype, cuda, monkeypatch):
+    """The v3 block with its three directions batched on the channel axis (one conv1d + one scan launch with
+    n_groups = 3, MambaInnerGroupedFnNoOutProj) against the reference's call pattern of three separate fused ops:
+    same output and same gradients for the input and every parameter."""
+    from mamba_ssm import Mamba
+    torch.manual_seed(5)
+    m = Mamba(d_model=64, d_state=16, d_conv=4, expand=2, bimamba_type="v3", nframes=5).to(cuda)
+    x = torch.randn(2, 5 * 48, 64, device=cuda)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("VIVIM_SEPARATE_DIRECTIONS", mode)
+        m.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=dtype, enabled=dtype != torch.float32):
+            y = m(xi)
+        y.float().square().mean().backward()
+        res[mode] = (y.detach().float(), xi.grad.float(), {n: p.grad.float().clone() for n, p in m.named_parameters()})
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-20))
+    assert rel(res["0"][0], res["1"][0]) < tol
+    assert rel(res["0"][1], res["1"][1]) < tol
+    for n in res["1"][2]:
+        assert rel(res["0"][2][n], res["1"][2][n]) < tol, n
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,D,nf,hw", [(2, 8, 5, 48), (1, 3, 3, 8), (3, 64, 5, 256), (2, 4, 1, 64), (1, 2, 8, 8)])
+def test_direction_maps_bit_exact(dtype, B, D, nf, hw, cuda):
+    """csrc/dirmap.hip against the torch ops it replaces (mamba_simple.py:231, 245-247, 261-264): the stack is a pure
+    permutation (bit-exact); the combine is (a + b + c) / 3 in fp32 (one rounding); both directions of autograd."""
+    from vivim_amd.dirmap import combine_directions, stack_directions
+    L = nf * hw
+    g = torch.Generator().manual_seed(B * 100 + D)
+    xz = torch.randn(2 * D, B, L, generator=g).to(dtype).to(cuda).transpose(0, 1)        # (L, B*L, 1)-strided like in_proj's
+    xz.requires_grad_(True)
+    stk = stack_directions(xz, nf)
+    assert stk.shape == (B, 2, 3, D, L)
+    xzv = xz.reshape(B, 2, D, L)
+    ref_s = xzv.reshape(B, 2, D, nf, hw).transpose(3, 4).reshape(B, 2, D, L)
+    assert torch.equal(stk[:, :, 0], xzv) and torch.equal(stk[:, :, 1], xzv.flip(-1)) and torch.equal(stk[:, :, 2], ref_s)
+    w = torch.randn(B, 2, 3, D, L, generator=g).to(dtype).to(cuda)
+    (gx,) = torch.autograd.grad(stk, xz, w)
+    wf = w.float()
+    ref_g = wf[:, :, 0] + wf[:, :, 1].flip(-1) + wf[:, :, 2].reshape(B, 2, D, hw, nf).transpose(3, 4).reshape(B, 2, D, L)
+    assert torch.equal(gx.reshape(B, 2, D, L), ref_g.to(dtype))
+    o3 = torch.randn(B, 3, D, L, generator=g).to(dtype).to(cuda).requires_grad_(True)
+    y = combine_directions(o3, nf)
+    of = o3.detach().float()
+    ref_y = (of[:, 0] + of[:, 1].flip(-1) + of[:, 2].reshape(B, D, hw, nf).transpose(2, 3).reshape(B, D, L)) * (1.0 / 3.0)
+    assert (y.float() - ref_y).abs().max() <= 2 * torch.finfo(dtype).eps * ref_y.abs().max()
+    gy = torch.randn(B, D, L, generator=g).to(dtype).to(cuda)
+    (go,) = torch.autograd.grad(y, o3, gy)
+    r = (gy.float() * (1.0 / 3.0)).to(dtype)
+    assert torch.equal(go[:, 0], r) and torch.equal(go[:, 1], r.flip(-1))
+    assert torch.equal(go[:, 2], r.reshape(B, D, nf, hw).transpose(2, 3).reshape(B, D, L))

@@ -79,10 +79,19 @@ class DwConvWgradParams(ctypes.Structure):
     )
 
 
+class DirParams(ctypes.Structure):
+    _fields_ = ([(n, i32) for n in ("batch", "channels", "seqlen", "nframes", "csplit", "itype")]
+                + [("scale", ctypes.c_float), ("_pad0", i32)]
+                + [(n, i64) for n in ("flat_batch_stride", "flat_c_stride", "stk_batch_stride", "stk_half_stride",
+                                      "stk_dir_stride", "stk_c_stride")]
+                + [("src", vp), ("dst", vp)])
+
+
 EXPORTS = ("vivim_abi_version", "vivim_last_error", "vivim_scan_chunk_len", "vivim_sizeof",
            "vivim_scan_bwd_workspace_bytes", "vivim_scan_fwd_workspace_bytes", "vivim_set_tuning",
            "vivim_selective_scan_fwd", "vivim_selective_scan_bwd",
-           "vivim_causal_conv1d_fwd", "vivim_causal_conv1d_bwd", "vivim_dwconv_fwd", "vivim_dwconv_wgrad")
+           "vivim_causal_conv1d_fwd", "vivim_causal_conv1d_bwd", "vivim_dwconv_fwd", "vivim_dwconv_wgrad",
+           "vivim_dir_scatter", "vivim_dir_gather")
 
 _lib = None
 
@@ -114,14 +123,15 @@ def lib():
             fn.argtypes = [ctypes.POINTER(SsmFwdParams)]
         for name, st in (("vivim_selective_scan_fwd", SsmFwdParams), ("vivim_selective_scan_bwd", SsmBwdParams),
                          ("vivim_causal_conv1d_fwd", ConvFwdParams), ("vivim_causal_conv1d_bwd", ConvBwdParams),
-                         ("vivim_dwconv_fwd", DwConvParams), ("vivim_dwconv_wgrad", DwConvWgradParams)):
+                         ("vivim_dwconv_fwd", DwConvParams), ("vivim_dwconv_wgrad", DwConvWgradParams),
+                         ("vivim_dir_scatter", DirParams), ("vivim_dir_gather", DirParams)):
             fn = getattr(L, name)
             fn.argtypes = [ctypes.POINTER(st), vp]
             fn.restype = ctypes.c_int
-        if L.vivim_abi_version() != 3:
+        if L.vivim_abi_version() != 4:
             raise ImportError("libvivim_hip.so ABI version mismatch")
         for which, st in enumerate((SsmFwdParams, SsmBwdParams, ConvFwdParams, ConvBwdParams, DwConvParams,
-                                    DwConvWgradParams)):
+                                    DwConvWgradParams, DirParams)):
             if L.vivim_sizeof(which) != ctypes.sizeof(st):
                 raise ImportError(f"struct layout mismatch for {st.__name__}: "
                                   f"C {L.vivim_sizeof(which)} vs ctypes {ctypes.sizeof(st)}")
@@ -147,6 +157,8 @@ def algorithmic_bytes(name, P):
         n_act = 5 + (3 if has_z else 0) + (1 if (has_z and f.out_z) else 0)   # u, delta, dout, du, ddelta (+ z, out, dz) (+ out_z)
         return (n_act * act + 2 * bc * (s if f.is_variable_B else 4) + 2 * bc * 4
                 + 4 * (2 * f.dim * f.dstate + 4 * f.dim))
+    if name.startswith("vivim_dir"):
+        return 4 * P.batch * P.channels * P.seqlen * _ISIZE[P.itype]  # one flat tensor + three stacked copies
     if name.startswith("vivim_dwconv"):
         act = P.batch * P.depth * P.height * P.width * P.channels * _ISIZE[P.itype]
         return 2 * act + 4 * P.channels * (P.kd * 9 + 1)            # x and y (or x and dy) once + taps

@@ -12,6 +12,7 @@ bool conv_bwd_dispatch(const vivim_conv_bwd_params&, hipStream_t);
 bool ssm_fwd_dispatch(const vivim_ssm_fwd_params&, hipStream_t);
 bool dwconv_fwd_dispatch(const vivim_dwconv_params&, hipStream_t);
 bool dwconv_wgrad_dispatch(const vivim_dwconv_wgrad_params&, hipStream_t);
+template <bool GATHER> bool dir_dispatch(const vivim_dir_params&, hipStream_t);     // dirmap.hip
 bool ssm_bwd_dispatch(const vivim_ssm_bwd_params&, hipStream_t);
 int scan_chunk_len(int itype);
 size_t scan_bwd_workspace_bytes(const vivim_ssm_fwd_params&);
@@ -102,6 +103,7 @@ size_t vivim_sizeof(int which) {
         case 3: return sizeof(vivim_conv_bwd_params);
         case 4: return sizeof(vivim_dwconv_params);
         case 5: return sizeof(vivim_dwconv_wgrad_params);
+        case 6: return sizeof(vivim_dir_params);
     }
     return 0;
 }
@@ -191,6 +193,33 @@ int vivim_dwconv_wgrad(const vivim_dwconv_wgrad_params* p, void* stream) {
     if (!vivim::dwconv_wgrad_dispatch(*p, static_cast<hipStream_t>(stream)))
         return fail(VIVIM_ERR_UNSUPPORTED, "dwconv_wgrad not implemented for input type %d", p->itype);
     return after_launch("dwconv_wgrad");
+}
+
+static int check_dir(const vivim_dir_params* p) {
+    VCHECK(p != nullptr);
+    VCHECK(p->itype == VIVIM_F32 || p->itype == VIVIM_F16 || p->itype == VIVIM_BF16);
+    VCHECK(p->batch > 0 && p->channels > 0 && p->seqlen > 0 && p->nframes > 0 && p->csplit > 0);
+    VCHECK(p->batch <= 65535 && p->channels <= 65535);
+    VCHECK(p->seqlen % p->nframes == 0 && p->channels % p->csplit == 0);
+    VCHECK(p->src && p->dst);
+    const int64_t e = p->itype == VIVIM_F32 ? 4 : 8;            // 16-byte vectors on both sides
+    VCHECK(p->seqlen % e == 0);
+    VCHECK((reinterpret_cast<uintptr_t>(p->src) & 15) == 0 && (reinterpret_cast<uintptr_t>(p->dst) & 15) == 0);
+    VCHECK(p->flat_batch_stride % e == 0 && p->flat_c_stride % e == 0 && p->stk_batch_stride % e == 0 &&
+           p->stk_half_stride % e == 0 && p->stk_dir_stride % e == 0 && p->stk_c_stride % e == 0);
+    return VIVIM_OK;
+}
+
+int vivim_dir_scatter(const vivim_dir_params* p, void* stream) {
+    if (int rc = check_dir(p)) return rc;
+    if (!vivim::dir_dispatch<false>(*p, static_cast<hipStream_t>(stream))) return fail(VIVIM_ERR_UNSUPPORTED, "dir_scatter: bad itype");
+    return after_launch("dir_scatter");
+}
+
+int vivim_dir_gather(const vivim_dir_params* p, void* stream) {
+    if (int rc = check_dir(p)) return rc;
+    if (!vivim::dir_dispatch<true>(*p, static_cast<hipStream_t>(stream))) return fail(VIVIM_ERR_UNSUPPORTED, "dir_gather: bad itype");
+    return after_launch("dir_gather");
 }
 
 }  // extern "C"

@@ -16,6 +16,7 @@ int tuning_bwd_variant();
 constexpr int kWave = 64;
 constexpr int kChunk = 256;   // tokens per row of the checkpoint tensor x (contract between fwd and bwd kernels)
 constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
 
 using f16_t = _Float16;
 using bf16_t = __bf16;

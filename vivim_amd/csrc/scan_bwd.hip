@@ -329,7 +329,9 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
         const int n = i / R, r = i - n * R;
         const float a = A[d[r] * f.A_d_stride + n * f.A_dstate_stride];
         float* q = rec + i * kRec;
-        q[GCAR] = (MODE == 0 && sg.S > 1) ? sg.gin[(((int64_t)b * f.dim + d[r]) * sg.S + seg) * N + n] : 0.0f;
+        // shadow slots (odd channel count, surplus waves) get no inflow either: with dy == 0 their g stays 0
+        q[GCAR] = (MODE == 0 && sg.S > 1 && active && r < nvalid)
+                      ? sg.gin[(((int64_t)b * f.dim + d[r]) * sg.S + seg) * N + n] : 0.0f;
         q[AFIRST] = fast_exp2((r == 0 ? dl_nx[0] : dl_nx[1]) * a * kLog2e);   // exp2(0) = 1 past the end
         q[AVAL] = a;
         q[A2VAL] = a * kLog2e;
@@ -362,11 +364,11 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
             const int n = i / R, r = i - n * R;
             rec[i * kRec + HCK] = step > 0 ? xck[(((int64_t)b * f.dim + d[r]) * nsteps + (step - 1)) * N + n] : 0.0f;
         }
-        float dl[R][K], w[R][K], uu[R][K], dy[R][K], S1[R][K], S2[R][K], dsum[R];
+        float dl[R][K], w[R][K], dy[R][K], S1[R][K], S2[R][K], dsum[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            float df[K], dof[K];
-            unpack(load_vec<T, K>(uB + d[r] * f.u_d_stride + t0, in && MODE == 0), uu[r]);
+            float df[K], dof[K], uu[K];                 // u is re-read for ddelta at the end of the step: 8 VGPRs less
+            unpack(load_vec<T, K>(uB + d[r] * f.u_d_stride + t0, in && MODE == 0), uu);
             unpack(load_vec<T, K>(dlB + d[r] * f.delta_d_stride + t0, in), df);
             unpack(load_vec<T, K>(doB + d[r] * p.dout_d_stride + t0, in), dof);
             if (HAS_Z) {
@@ -396,11 +398,11 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
                 const float sp = f.delta_softplus ? softplus_ref(raw) : raw;
                 dl[r][k] = in ? sp : 0.0f;              // padded tokens: identity maps both ways
                 dsum[r] += dl[r][k];
-                w[r][k] = dl[r][k] * uu[r][k];
-                dy[r][k] = dof[k];
+                w[r][k] = dl[r][k] * uu[k];
+                dy[r][k] = dof[k] * msk[r];            // shadow slots / surplus waves: g == 0, dB = dC = dA = 0
                 S1[r][k] = 0.0f;
                 S2[r][k] = 0.0f;
-                dD_acc[r] = fmaf(dof[k], uu[r][k], dD_acc[r]);
+                dD_acc[r] = fmaf(dof[k], uu[k], dD_acc[r]);
             }
             if (MODE == 1) {
                 dtot[r] += dsum[r];
@@ -423,11 +425,13 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
                     Craw = load_vec_always<T, K>(Cv + (n + 1) * f.C_dstate_stride + t0, nx, Cv);
                 }
                 if (n == 1) VIVIM_STAMP(nsteps - 1 - step, 11, wave, lane);
-                float q[R][kRec];
+                float q[R][kRec];                      // HCK, GCAR, AFIRST, (AVAL), A2VAL: one 16-byte read + one float
 #pragma unroll
-                for (int r = 0; r < R; ++r)
+                for (int r = 0; r < R; ++r) {
 #pragma unroll
-                    for (int j = 0; j < kRec; ++j) q[r][j] = rec[(n * R + r) * kRec + j];
+                    for (int j = 0; j < 4; ++j) q[r][j] = rec[(n * R + r) * kRec + j];
+                    q[r][A2VAL] = rec[(n * R + r) * kRec + A2VAL];
+                }
                 if (n == 1) VIVIM_STAMP(nsteps - 1 - step, 12, wave, lane);
                 // ---- forward re-scan ----
                 float a[R][K], hs[R][K], P[R], H[R];
@@ -488,10 +492,10 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
                         const float ahp = hs[r][k] - w[r][k] * Bn[k];        // a_t h_{t-1}
                         const float t = gc * ahp;
                         S1[r][k] = fmaf(gc, Bn[k], S1[r][k]);                // du = D dy + d * S1
-                        S2[r][k] = fmaf(t, q[r][AVAL], S2[r][k]);            // dd = u * S1 + S2
+                        S2[r][k] = fmaf(t, q[r][A2VAL], S2[r][k]);           // dd = u * S1 + ln2 * S2
                         dA_part = fmaf(t, dl[r][k], dA_part);
-                        dBv[k] = fmaf(gc * msk[r], w[r][k], dBv[k]);
-                        dCv[k] = fmaf(dy[r][k] * msk[r], hs[r][k], dCv[k]);
+                        dBv[k] = fmaf(gc, w[r][k], dBv[k]);                  // shadow slots: dy == 0, so gc == 0
+                        dCv[k] = fmaf(dy[r][k], hs[r][k], dCv[k]);
                     }
                     const float dA_tot = MODE == 0 ? read_lane(wave_sum_dpp_to63(dA_part), 63) : 0.0f;
                     const float g0 = read_lane(gfirst, 0), a0 = read_lane(a[r][0], 0);
@@ -499,7 +503,7 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
                         float* qq = rec + (n * R + r) * kRec;
                         qq[GCAR] = g0;                                       // g at this step's first token
                         qq[AFIRST] = a0;
-                        qq[DAACC] = q[r][DAACC] + dA_tot;
+                        qq[DAACC] += dA_tot;
                     }
                 }
                 if (n == 1) VIVIM_STAMP(nsteps - 1 - step, 14, wave, lane);
@@ -536,11 +540,12 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
         if (MODE == 0)
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            float duv[K], ddv[K];
+            float duv[K], ddv[K], uu[K];
+            unpack(load_vec<T, K>(uB + d[r] * f.u_d_stride + t0, in), uu);
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 duv[k] = fmaf(dl[r][k], S1[r][k], Dv[r] * dy[r][k]);
-                ddv[k] = fmaf(uu[r][k], S1[r][k], S2[r][k]);
+                ddv[k] = fmaf(uu[k], S1[r][k], S2[r][k] * kLn2);         // S2 was accumulated with A * log2e
             }
             if (f.delta_softplus) {                                           // bwd_kernel.cuh:439-452
                 // sigmoid(raw) = 1 - exp(-softplus(raw)); exact for raw > 20 too (softplus = raw there, and
@@ -595,6 +600,137 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
                 atomicAdd(static_cast<float*>(p.dA) + (d0 + r) * p.dA_d_stride + n * p.dA_dstate_stride,
                           rec[i * kRec + DAACC]);
         }
+    }
+}
+
+// ---- pre-pass of the token-axis split: per (batch, channel, segment >= 1, state) the reverse aggregate ----------
+//   agg  = g at the segment's first token t0 for zero inflow from the right
+//        = sum_{t in seg} (prod_{tau = t0+1 .. t} a_tau) * C_{n,t} * dy_t,   a_tau = exp(delta_tau * A_n)
+//        = sum_t exp2(A_n * log2e * (cdelta_t - delta_{t0})) * C_{n,t} * dy_t      (cdelta = inclusive prefix of delta)
+//   dsum = sum_{t in seg} delta_{t+1}
+// One prefix sum of delta per channel serves all N states, so a state update costs mul + exp + fma here instead of
+// the two scans of the main kernel (SQ counters: 18 VALU lane-instructions per update when the pre-pass was the
+// main kernel with its outputs switched off).  exp2 of a large negative argument underflows to 0
+// exactly where the true weight is negligible.  A wave owns a channel pair and one segment; lane = K consecutive
+// tokens of a 256-token step; the running sums live in wave-private LDS [state][channel][lane] because the state
+// loop cannot be unrolled for a run-time N; they are reduced over the lanes once per segment.
+constexpr int kPreW = 4;           // independent waves per workgroup (fewer when N * 512 bytes per wave would pass 64 KB)
+template <typename T, int K, bool HAS_Z>
+__global__ void __launch_bounds__(kPreW * kWave) ssm_bwd_prepass_kernel(const vivim_ssm_bwd_params p, const BwdSeg sg) {
+    constexpr int R = kBwR;
+    constexpr int TILE = kWave * K;
+    const vivim_ssm_fwd_params& f = p.f;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    const int N = f.dstate, L = f.seqlen;
+    const int cpg = f.dim / f.n_groups;
+    const int ppg = (cpg + R - 1) / R;                 // channel pairs per B/C group
+    const int nw = blockDim.x >> 6;                    // waves in this workgroup
+    const int bpg = (ppg + nw - 1) / nw;
+    const int g = blockIdx.x / bpg;
+    const int pair = (blockIdx.x - g * bpg) * nw + wave;
+    if (pair >= ppg) return;                           // waves are independent: no workgroup barrier below
+    const int d0 = g * cpg + pair * R;
+    const int nvalid = min(R, (g + 1) * cpg - d0);
+    const int nsteps = (L + TILE - 1) / TILE;
+    const int seg = blockIdx.z + 1;                    // segment 0 has no left neighbour to feed
+    const int s_lo = seg * sg.seg_steps, s_hi = min(nsteps, s_lo + sg.seg_steps);
+    const int t_next = s_hi * TILE;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* acc = smem + wave * (N * R * kWave);        // [n][r][lane]
+    for (int i = lane; i < N * R * kWave; i += kWave) acc[i] = 0.0f;
+
+    int d[R];
+    float bias[R], a2v[R];                             // a2v: lane n holds A[d][n] * log2e
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        d[r] = d0 + min(r, nvalid - 1);
+        bias[r] = f.delta_bias ? static_cast<const float*>(f.delta_bias)[d[r]] : 0.0f;
+        a2v[r] = lane < N ? static_cast<const float*>(f.A)[d[r] * f.A_d_stride + lane * f.A_dstate_stride] * kLog2e : 0.0f;
+    }
+    const T* __restrict__ dlB = static_cast<const T*>(f.delta) + b * f.delta_batch_stride;
+    const T* __restrict__ doB = static_cast<const T*>(p.dout) + b * p.dout_batch_stride;
+    const T* __restrict__ zB = HAS_Z ? static_cast<const T*>(f.z) + b * f.z_batch_stride : nullptr;
+    const T* __restrict__ Cv = static_cast<const T*>(f.C) + b * f.C_batch_stride + g * f.C_group_stride;
+    wave_lds_fence();
+
+    float base[R] = {0.0f, 0.0f}, dfirst[R] = {0.0f, 0.0f};
+    for (int step = s_lo; step < s_hi; ++step) {
+        const int t0 = step * TILE + lane * K;
+        const bool in = t0 < L;                         // L % K == 0 (host): a lane is all-in or all-out
+        float c[R][K], dy[R][K];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float df[K];
+            unpack(load_vec<T, K>(dlB + d[r] * f.delta_d_stride + t0, in), df);
+            unpack(load_vec<T, K>(doB + d[r] * p.dout_d_stride + t0, in), dy[r]);
+            if (HAS_Z) {
+                float zf[K];
+                unpack(load_vec<T, K>(zB + d[r] * f.z_d_stride + t0, in), zf);
+#pragma unroll
+                for (int k = 0; k < K; ++k) dy[r][k] *= zf[k] * sigmoidf_fast(zf[k]);
+            }
+            float run = 0.0f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float raw = df[k] + bias[r];
+                const float sp = f.delta_softplus ? softplus_ref(raw) : raw;
+                run += in ? sp : 0.0f;                  // padded tokens: delta 0 (and dy 0: they add nothing)
+                c[r][k] = run;
+            }
+            if (step == s_lo) {
+                dfirst[r] = read_lane(c[r][0], 0);      // delta of the segment's first token
+                base[r] = -dfirst[r];
+            }
+            const float incl = wave_sum_dpp_to63(run);  // inclusive prefix of the lane totals
+            const float off = incl - run + base[r];
+#pragma unroll
+            for (int k = 0; k < K; ++k) c[r][k] += off;
+            base[r] += read_lane(incl, 63);
+        }
+        RawK<T, K> Craw = load_vec_always<T, K>(Cv + t0, in, Cv);
+#pragma unroll 1
+        for (int n = 0; n < N; ++n) {
+            float Cn[K];
+            unpack(Craw, Cn);
+            Craw = load_vec_always<T, K>(Cv + (n + 1) * f.C_dstate_stride + t0, in && (n + 1 < N), Cv);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float A2 = read_lane(a2v[r], n);
+                float* q = acc + (n * R + r) * kWave + lane;
+                float v = *q;
+#pragma unroll
+                for (int k = 0; k < K; ++k) v = fmaf(fast_exp2(A2 * c[r][k]), Cn[k] * dy[r][k], v);
+                *q = v;
+            }
+        }
+    }
+    wave_lds_fence();
+    // lane pair (2i, 2i+1) sums the 64 partials of row i = (n, r): 32 rows per sweep
+    for (int row0 = 0; row0 < N * R; row0 += kWave / 2) {
+        const int row = row0 + (lane >> 1);
+        float v = 0.0f;
+        if (row < N * R) {
+            const float* q = acc + row * kWave + (lane & 1) * (kWave / 2);
+#pragma unroll 8
+            for (int j = 0; j < kWave / 2; ++j) v += q[j];
+        }
+        v += __shfl_xor(v, 1, kWave);
+        const int n = row / R, r = row - n * R;
+        if (row < N * R && (lane & 1) == 0 && r < nvalid)
+            sg.agg[(((int64_t)b * f.dim + d0 + r) * sg.S + seg) * N + n] = v;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float dl_nx = 0.0f;                             // softplus(delta + bias) at the first token of the next segment
+        if (t_next < L) {
+            const float raw = to_f32<T>((dlB + d[r] * f.delta_d_stride)[t_next]) + bias[r];
+            dl_nx = f.delta_softplus ? softplus_ref(raw) : raw;
+        }
+        // base = (sum of delta over the segment) - delta_first  ->  sum_{t in seg} delta_{t+1}
+        if (lane == 0 && r < nvalid) sg.dsum[((int64_t)b * f.dim + d[r]) * sg.S + seg] = base[r] + dl_nx;
     }
 }
 
@@ -656,9 +792,12 @@ static void launch_bwd_fast(const vivim_ssm_bwd_params& p, hipStream_t stream) {
     const dim3 block(kBwW * kWave);
     const size_t smem = ((size_t)2 * kBwW * 2 * K * kWave + (size_t)kBwW * f.dstate * kBwR * kRec) * sizeof(float);
     if (sg.S > 1) {
-        dim3 gpre(bpg * f.n_groups, f.batch, sg.S - 1);
-        if (f.z) hipLaunchKernelGGL((ssm_bwd_fast_kernel<T, K, true, MINW, 1>), gpre, block, smem, stream, p, sg);
-        else     hipLaunchKernelGGL((ssm_bwd_fast_kernel<T, K, false, MINW, 1>), gpre, block, smem, stream, p, sg);
+        const size_t per_wave = (size_t)f.dstate * kBwR * kWave * sizeof(float);            // 8 KB at N = 16, 32 KB at N = 64
+        int nw = (int)((size_t)65536 / per_wave);
+        nw = nw > kPreW ? kPreW : (nw < 1 ? 1 : nw);
+        dim3 gpre(((ppg + nw - 1) / nw) * f.n_groups, f.batch, sg.S - 1);
+        if (f.z) hipLaunchKernelGGL((ssm_bwd_prepass_kernel<T, K, true>), gpre, dim3(nw * kWave), nw * per_wave, stream, p, sg);
+        else     hipLaunchKernelGGL((ssm_bwd_prepass_kernel<T, K, false>), gpre, dim3(nw * kWave), nw * per_wave, stream, p, sg);
         const int64_t nthr = (int64_t)f.batch * f.dim * f.dstate;
         hipLaunchKernelGGL(ssm_bwd_carry_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream, p, sg);
     }

@@ -15,7 +15,10 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .selective_scan_interface import mamba_inner_fn_no_out_proj
+import os
+
+from .dirmap import combine_directions, stack_directions
+from .selective_scan_interface import mamba_inner_fn_no_out_proj, mamba_inner_grouped_fn_no_out_proj
 
 _DIRECTIONS = ("", "_b", "_s")     # forward in time, backward in time, spatial (pixel-major) order
 
@@ -91,10 +94,32 @@ class Mamba(nn.Module):
               ).view(2 * self.d_inner, batch, seqlen).transpose(0, 1)
         if self.in_proj.bias is not None:
             xz = xz + self.in_proj.bias.to(xz.dtype)[:, None]
+        hw = seqlen // nf
+        # the direction-map kernels move whole 16-byte vectors: token counts that are not a multiple of 8 (never the
+        # case for Vivim's H*W = 64 * k) take the reference's three-call composition with torch flips / permutes
+        if os.environ.get("VIVIM_SEPARATE_DIRECTIONS", "0") == "1" or seqlen % 8 != 0:
+            return self._forward_separate(xz, batch, seqlen, nf, hw)
+        # The three directions side by side on the channel axis -> ONE conv1d launch and ONE scan launch
+        # (n_groups = 3) per block instead of three of each (selective_scan_interface.MambaInnerGroupedFnNoOutProj).
+        D = self.d_inner
+        xz3 = stack_directions(xz, nf)                    # (B, 2, 3, D, L): identity / flip / frame interleave, one read
+        cat = lambda name: torch.cat([getattr(self, name + sfx) for sfx in _DIRECTIONS])
+        conv_w = torch.cat([getattr(self, "conv1d" + sfx).weight for sfx in _DIRECTIONS]).squeeze(1)
+        conv_b = (torch.cat([getattr(self, "conv1d" + sfx).bias for sfx in _DIRECTIONS])
+                  if self.conv1d.bias is not None else None)
+        x_proj_w = torch.stack([getattr(self, "x_proj" + sfx).weight for sfx in _DIRECTIONS])
+        dt_proj_w = torch.stack([getattr(self, "dt_proj" + sfx).weight for sfx in _DIRECTIONS])
+        dt_bias = torch.cat([getattr(self, "dt_proj" + sfx).bias for sfx in _DIRECTIONS]).float()
+        A = -torch.exp(torch.cat([getattr(self, f"A{sfx}_log") for sfx in _DIRECTIONS]).float())
+        o3 = mamba_inner_grouped_fn_no_out_proj(xz3, conv_w, conv_b, x_proj_w, dt_proj_w, A, cat("D").float(),
+                                                dt_bias, True).view(batch, 3, D, seqlen)
+        y = combine_directions(o3, nf).transpose(1, 2)    # (out + out_b.flip + out_s^-1) / 3, one write
+        return F.linear(y, self.out_proj.weight, self.out_proj.bias)
+
+    def _forward_separate(self, xz, batch, seqlen, nf, hw):
+        """The reference's call pattern: three `mamba_inner_fn_no_out_proj` calls (mamba_simple.py:220-262)."""
         out = self._inner(xz, "")
         out_b = self._inner(xz.flip([-1]), "_b").flip([-1])
-        hw = seqlen // nf
-        # token t*hw + p  ->  p*nf + t  (what chunk(nf) + stack(-1) + flatten does, mamba_simple.py:245-247)
         xz_s = xz.reshape(batch, 2 * self.d_inner, nf, hw).transpose(2, 3).reshape(batch, 2 * self.d_inner, seqlen)
         out_s = self._inner(xz_s, "_s")
         out_s = out_s.reshape(batch, self.d_inner, hw, nf).transpose(2, 3).reshape(batch, self.d_inner, seqlen)
