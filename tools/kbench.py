@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Kernel micro-benchmark: times the four hot-path kernels (through the C ABI) on the stage shapes of a
 BASELINE.json config and prints achieved algorithmic GB/s (SURVEY.md section 8d formulas).
-Usage: python tools/kbench.py [--config 2|3|5] [--iters 20] [--stages 0,1,2,3] [--kernels sf,sb,cf,cb]"""
+Usage: python tools/kbench.py [--config 2|3|5] [--iters 20] [--stages 0,1,2,3] [--kernels sf,sb,cf,cb] [--groups 3]
+--groups 3: the grouped v3 shapes (three directions side by side: dim = 3 * d_inner, n_groups = 3, contiguous rows)."""
 import argparse
 import os
 import sys
@@ -49,19 +50,21 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--stages", default="0,1,2,3")
     ap.add_argument("--kernels", default="sf,sb,cf,cb")
+    ap.add_argument("--groups", type=int, default=1)
     a = ap.parse_args()
     B, nf, img, N, expand, dt = CONFIGS[a.config]
     s = torch.finfo(dt).bits // 8
     dev = torch.device("cuda:0")
     print(f"config {a.config}: B={B} nf={nf} img={img} N={N} expand={expand} dtype={dt}")
     for st in map(int, a.stages.split(",")):
-        D = DIMS[st] * expand
+        G = a.groups
+        D = DIMS[st] * expand * G
         L = nf * (img // STRIDES[st]) ** 2
         mk = lambda *sh: torch.randn(*sh, device=dev).to(dt)
-        strided = lambda: mk(D, B, L).transpose(0, 1)
-        u, delta, z, dout = strided(), (0.2 * torch.randn(D, B, L, device=dev)).to(dt).transpose(0, 1), strided(), strided()
+        strided = (lambda: mk(D, B, L).transpose(0, 1)) if G == 1 else (lambda: mk(B, D, L))
+        u, delta, z, dout = strided(), ((0.2 * torch.randn(D, B, L, device=dev)).to(dt).transpose(0, 1) if G == 1 else (0.2 * torch.randn(B, D, L, device=dev)).to(dt)), strided(), strided()
         A = -torch.arange(1, N + 1, device=dev, dtype=torch.float32).repeat(D, 1)
-        Bm, Cm = mk(B, 1, N, L), mk(B, 1, N, L)
+        Bm, Cm = mk(B, G, N, L), mk(B, G, N, L)
         Dv, bias = torch.ones(D, device=dev), torch.full((D,), -4.0, device=dev)
         w, cb = torch.randn(D, 4, device=dev), torch.randn(D, device=dev)
         out, x, out_z = ss.fwd(u, delta, A, Bm, Cm, Dv, z, bias, True)
@@ -74,7 +77,7 @@ def main():
         }
         for k in a.kernels.split(","):
             t = timeit(runs[k], a.iters)
-            nb = alg_bytes(k, B, D, L, N, s)
+            nb = alg_bytes(k, B, D, L, N, s, G)
             print(f"  stage {st} D={D:5d} L={L:6d} {k}: {t * 1e6:9.1f} us  {nb / 1e6:8.1f} MB  {nb / t / 1e9:8.1f} GB/s "
                   f"({nb / t / 8e12 * 100:5.1f}% of 8 TB/s)", flush=True)
 

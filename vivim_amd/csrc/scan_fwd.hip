@@ -403,9 +403,12 @@ static bool try_fwd_nsplit(const vivim_ssm_fwd_params& p, hipStream_t stream) {
         return false;
     const int forced = tuning_fwd_variant();
     // 512-token steps (K=8) halve the per-step fixed cost; 256-token steps (K=4) need 100 instead of 160 VGPRs,
-    // so several workgroups share a CU -- better once there are enough workgroups to fill the chip twice.
+    // so several workgroups share a CU -- better once there are enough workgroups to fill the chip twice AND the
+    // rows are short (few steps per row: finer steps waste less of the last one).
     const int64_t nwg = (int64_t)((p.dim / p.n_groups + kNsR - 1) / kNsR) * p.n_groups * p.batch;
-    int variant = (forced && forced != 5) ? forced : (nwg >= 512 ? 2 : 1);
+    // Measured at the grouped v3 shapes (dim = 3 * d_inner, tools/kbench.py --groups 3): K=8 wins for long rows (L 20480:
+    // 365 vs 503 us, L 5120: 160 vs 188 us), K=4 for short ones (L 1280: 112 vs 130 us, L 320: 68 vs 87 us).
+    int variant = (forced && forced != 5) ? forced : ((nwg >= 512 && p.seqlen < 4096) ? 2 : 1);
     switch (variant) {
         case 2:  launch_fwd_nsplit<T, 4, 8, 2>(p, stream); break;     // K=4
         case 3:  return false;                                         // generic kernel (tuning only)
