@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define VIVIM_ABI_VERSION 4
+#define VIVIM_ABI_VERSION 5
 
 typedef enum { VIVIM_F32 = 0, VIVIM_F16 = 1, VIVIM_BF16 = 2 } vivim_dtype_t;
 
@@ -185,11 +185,53 @@ typedef struct {
     void *dst;
 } vivim_dir_params;
 
+/* ---- single-token steps for streaming inference ------------------------------------------
+ * causal_conv1d_update (causal_conv1d.cpp:270-327, causal_conv1d_update.cu:26-66): conv_state is shifted left by one
+ * along width, x is appended, out = sum_w conv_state[w] * weight[w] (+ bias) (silu). */
+typedef struct {
+    int32_t batch, dim, width;           /* width in [2, 4] */
+    int32_t itype;                       /* x, conv_state, out */
+    int32_t wtype;                       /* weight, bias */
+    int32_t silu_activation;
+    int64_t x_batch_stride, x_c_stride;
+    int64_t state_batch_stride, state_c_stride, state_w_stride;
+    int64_t weight_c_stride, weight_width_stride;
+    int64_t out_batch_stride, out_c_stride;
+    const void *x;              /* (batch, dim) */
+    void *conv_state;           /* (batch, dim, width), updated in place */
+    const void *weight;         /* (dim, width) */
+    const void *bias;           /* (dim) or NULL */
+    void *out;                  /* (batch, dim) */
+} vivim_conv_update_params;
+
+/* selective_state_update (mamba_ssm/ops/triton/selective_state_update.py:21-155): dt' = (softplus)(dt + dt_bias);
+ * state = state * exp(dt' * A) + dt' * B * x (in place); out = sum_n state * C + D * x, gated by silu(z). */
+typedef struct {
+    int32_t batch, dim, dstate;
+    int32_t itype;                       /* x, dt, B, C, z, out */
+    int32_t stype;                       /* state: VIVIM_F32 or the same as itype */
+    int32_t dt_softplus;
+    int64_t state_batch_stride, state_d_stride, state_n_stride;
+    int64_t x_batch_stride, x_d_stride, dt_batch_stride, dt_d_stride;
+    int64_t A_d_stride, A_n_stride;
+    int64_t B_batch_stride, B_n_stride, C_batch_stride, C_n_stride;
+    int64_t z_batch_stride, z_d_stride, out_batch_stride, out_d_stride;
+    void *state;                /* (batch, dim, dstate), updated in place */
+    const void *x, *dt;         /* (batch, dim) */
+    const void *A;              /* (dim, dstate) f32 */
+    const void *B, *C;          /* (batch, dstate) */
+    const void *D;              /* (dim) f32 or NULL */
+    const void *z;              /* (batch, dim) or NULL */
+    const void *dt_bias;        /* (dim) f32 or NULL */
+    void *out;                  /* (batch, dim) */
+} vivim_state_update_params;
+
 int vivim_abi_version(void);
 const char *vivim_last_error(void);
 
 /* sizeof() of a params struct as this library was compiled, so a foreign-language binding can assert
- * its own layout: which = 0 ssm_fwd, 1 ssm_bwd, 2 conv_fwd, 3 conv_bwd, 4 dwconv, 5 dwconv_wgrad, 6 dir; 0 for anything else. */
+ * its own layout: which = 0 ssm_fwd, 1 ssm_bwd, 2 conv_fwd, 3 conv_bwd, 4 dwconv, 5 dwconv_wgrad, 6 dir, 7 conv_update,
+ * 8 state_update; 0 for anything else. */
 size_t vivim_sizeof(int which);
 
 /* Tokens per checkpoint row of `x` for an input dtype; n_chunks = ceil(seqlen / chunk_len). */
@@ -216,6 +258,8 @@ int vivim_dwconv_fwd(const vivim_dwconv_params *p, void *stream);            /* 
 int vivim_dwconv_wgrad(const vivim_dwconv_wgrad_params *p, void *stream);
 int vivim_dir_scatter(const vivim_dir_params *p, void *stream);
 int vivim_dir_gather(const vivim_dir_params *p, void *stream);
+int vivim_causal_conv1d_update(const vivim_conv_update_params *p, void *stream);
+int vivim_selective_state_update(const vivim_state_update_params *p, void *stream);
 
 #ifdef __cplusplus
 }

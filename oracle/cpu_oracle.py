@@ -115,3 +115,26 @@ def causal_conv1d_bwd(x, weight, bias, dout, silu=False):
     _load().oracle_causal_conv1d_bwd(_p(x), _p(weight), _p(bias), _p(dout), int(silu), batch, dim, L,
                                      weight.shape[1], _p(dx), _p(dw), _p(db))
     return dx, dw, db
+
+
+def causal_conv1d_update(x, conv_state, weight, bias=None, silu=False):
+    """causal_conv1d_update_ref (causal_conv1d_interface.py:83-104) -> (out, new_conv_state) float32 CPU tensors
+    (the input state is not modified)."""
+    x, conv_state, weight, bias = map(_f32, (x, conv_state, weight, bias))
+    conv_state = conv_state.clone()
+    batch, dim = x.shape
+    out = torch.empty_like(x)
+    _load().oracle_causal_conv1d_update(_p(x), _p(conv_state), _p(weight), _p(bias), int(silu), batch, dim,
+                                        weight.shape[1], _p(out))
+    return out, conv_state
+
+
+def selective_state_update(state, x, dt, A, B, C, D=None, z=None, dt_bias=None, dt_softplus=False):
+    """selective_state_update_ref (selective_state_update.py:157-192) -> (out, new_state) float32 CPU tensors."""
+    state, x, dt, A, B, C, D, z, dt_bias = map(_f32, (state, x, dt, A, B, C, D, z, dt_bias))
+    state = state.clone()
+    batch, dim, dstate = state.shape
+    out = torch.empty_like(x)
+    _load().oracle_selective_state_update(_p(state), _p(x), _p(dt), _p(A), _p(B), _p(C), _p(D), _p(z), _p(dt_bias),
+                                          int(dt_softplus), batch, dim, dstate, _p(out))
+    return out, state

@@ -192,7 +192,7 @@ def make_inner(ssi):
              meta=np.array([b, d_inner, n, r, l]))
 
 
-def make_module(cci, ssi):
+def make_module(cci, ssi, only=None):
     """v3 Mamba module forward/backward (mamba_simple.py:188-264).  The module's fast path calls
     mamba_inner_fn_no_out_proj (CUDA); it is rebound to the reference refs composed as in make_inner."""
     ms = _load("mamba_ssm.modules.mamba_simple", f"{REF}/mamba/mamba_ssm/modules/mamba_simple.py")
@@ -207,7 +207,13 @@ def make_module(cci, ssi):
     ms.mamba_inner_fn_no_out_proj = no_out_proj_via_refs
     for i, (name, b, d_model, n, expand, nf, hw) in enumerate([("module_nf5", 2, 8, 4, 2, 5, 6),
                                                                ("module_nf3", 1, 8, 4, 2, 3, 4),
-                                                               ("module_nf1", 1, 16, 8, 2, 1, 9)]):
+                                                               ("module_nf1", 1, 16, 8, 2, 1, 9),
+                                                               # token counts that are multiples of 8: the build's
+                                                               # grouped three-direction path (vivim_amd/mamba_simple.py)
+                                                               ("module_nf5_hw8", 2, 16, 16, 2, 5, 8),
+                                                               ("module_nf3_hw16", 1, 32, 16, 2, 3, 16)]):
+        if only and name not in only:
+            continue
         torch.manual_seed(400 + i)
         m = ms.Mamba(d_model=d_model, d_state=n, d_conv=4, expand=expand, bimamba_type="v3", nframes=nf)
         G = gen(450 + i)
@@ -227,10 +233,54 @@ def make_module(cci, ssi):
              meta=np.array([b, d_model, n, expand, nf, hw]))
 
 
+def make_update(cci):
+    """Single-token steps: causal_conv1d_update_ref (causal_conv1d_interface.py:83-104) and
+    selective_state_update_ref (mamba_ssm/ops/triton/selective_state_update.py:157-192; the module imports triton at
+    the top, which is installed here; only the pure-PyTorch ref is called)."""
+    ssu = _load("ref_selective_state_update", f"{REF}/mamba/mamba_ssm/ops/triton/selective_state_update.py")
+    for i, (name, b, d, w, hb, silu, dt) in enumerate([("update_conv_w4", 2, 96, 4, 1, 1, "fp32"),
+                                                       ("update_conv_w2_plain", 3, 5, 2, 0, 0, "fp32"),
+                                                       ("update_conv_w3_bf16", 2, 64, 3, 1, 1, "bf16")]):
+        G = gen(600 + i)
+        dtype = DT[dt]
+        x = cast(torch.randn(b, d, generator=G), dtype)
+        st = cast(torch.randn(b, d, w, generator=G), dtype)
+        wt = torch.randn(d, w, generator=G)
+        bias = torch.randn(d, generator=G) if hb else None
+        st_new = st.clone()
+        out = cci.causal_conv1d_update_ref(x, st_new, wt, bias, "silu" if silu else None)
+        save(name, x=npf(x), conv_state=npf(st), weight=npf(wt), bias=npf(bias), out=npf(out), conv_state_new=npf(st_new),
+             meta=np.array([b, d, w, hb, silu]), dtype=np.array(dt))
+    for i, (name, b, d, n, hD, hZ, hb, sp, dt) in enumerate([("update_ssm_n16", 2, 64, 16, 1, 1, 1, 1, "fp32"),
+                                                             ("update_ssm_plain", 1, 7, 8, 0, 0, 0, 0, "fp32"),
+                                                             ("update_ssm_n64_bf16", 2, 32, 64, 1, 1, 1, 1, "bf16")]):
+        G = gen(650 + i)
+        dtype = DT[dt]
+        state = torch.randn(b, d, n, generator=G)                       # fp32 state, as Mamba.step keeps it
+        x = cast(torch.randn(b, d, generator=G), dtype)
+        dtv = cast(0.5 * torch.rand(b, d, generator=G), dtype)
+        A = -0.5 * torch.rand(d, n, generator=G) - 0.05
+        Bm, Cm = cast(torch.randn(b, n, generator=G), dtype), cast(torch.randn(b, n, generator=G), dtype)
+        D = torch.randn(d, generator=G) if hD else None
+        z = cast(torch.randn(b, d, generator=G), dtype) if hZ else None
+        bias = 0.5 * torch.rand(d, generator=G) if hb else None
+        st_new = state.clone()
+        out = ssu.selective_state_update_ref(st_new, x, dtv, A, Bm, Cm, D=D, z=z, dt_bias=bias, dt_softplus=bool(sp))
+        save(name, state=npf(state), x=npf(x), dt=npf(dtv), A=npf(A), B=npf(Bm), C=npf(Cm), D=npf(D), z=npf(z),
+             dt_bias=npf(bias), out=npf(out), state_new=npf(st_new), meta=np.array([b, d, n, hD, hZ, hb, sp]),
+             dtype=np.array(dt))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     cci, ssi = load_reference()
-    make_scan(ssi)
-    make_conv(cci)
-    make_inner(ssi)
-    make_module(cci, ssi)
+    only = set(sys.argv[1:])          # e.g. `make_golden.py update module_nf5_hw8` regenerates just those
+    if not only:
+        make_scan(ssi)
+        make_conv(cci)
+        make_inner(ssi)
+    if not only or "update" in only:
+        make_update(cci)
+    mods = {n for n in only if n.startswith("module_")}
+    if not only or mods:
+        make_module(cci, ssi, mods or None)

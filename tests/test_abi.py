@@ -27,10 +27,11 @@ def test_header_symbols_exported():
 def test_struct_layouts_match():
     L = _lib.lib()
     for which, st in enumerate((_lib.SsmFwdParams, _lib.SsmBwdParams, _lib.ConvFwdParams, _lib.ConvBwdParams,
-                                _lib.DwConvParams, _lib.DwConvWgradParams, _lib.DirParams)):
+                                _lib.DwConvParams, _lib.DwConvWgradParams, _lib.DirParams, _lib.ConvUpdateParams,
+                                _lib.StateUpdateParams)):
         assert L.vivim_sizeof(which) == ctypes.sizeof(st)
     assert L.vivim_sizeof(99) == 0
-    assert L.vivim_abi_version() == 4
+    assert L.vivim_abi_version() == 5
     assert L.vivim_scan_chunk_len(_lib.F32) > 0 and L.vivim_scan_chunk_len(_lib.BF16) % 64 == 0
 
 

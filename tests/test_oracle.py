@@ -98,3 +98,26 @@ def test_v3_module_matches_reference(name):
     assert rel_err(x.grad, g["dx"]) < 1e-4
     for k, v in p.items():
         assert rel_err(v.grad, g["grad__" + k.replace(".", "__")]) < 2e-4, k
+
+
+@pytest.mark.parametrize("name", golden_names("update_conv_"))
+def test_c_conv_update_matches_reference(name):
+    """oracle_causal_conv1d_update against causal_conv1d_update_ref fixtures (causal_conv1d_interface.py:83-104)."""
+    g = load_golden(name)
+    silu = bool(g["meta"][4])
+    out, st = cpu_oracle.causal_conv1d_update(g["x"], g["conv_state"], g["weight"], _opt(g, "bias"), silu)
+    tol = TOL32 if g["dtype"] == "fp32" else TOL16[g["dtype"]]
+    assert rel_err(out, g["out"]) < tol
+    assert torch.equal(st, g["conv_state_new"])            # a pure shift: bit-exact
+
+
+@pytest.mark.parametrize("name", golden_names("update_ssm_"))
+def test_c_state_update_matches_reference(name):
+    """oracle_selective_state_update against selective_state_update_ref fixtures (selective_state_update.py:157-192)."""
+    g = load_golden(name)
+    sp = bool(g["meta"][6])
+    out, st = cpu_oracle.selective_state_update(g["state"], g["x"], g["dt"], g["A"], g["B"], g["C"], _opt(g, "D"),
+                                                _opt(g, "z"), _opt(g, "dt_bias"), sp)
+    tol = TOL32 if g["dtype"] == "fp32" else TOL16[g["dtype"]]
+    assert rel_err(out, g["out"]) < tol
+    assert rel_err(st, g["state_new"]) < (TOL32 if g["dtype"] == "fp32" else 1e-2)

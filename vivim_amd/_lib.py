@@ -87,11 +87,28 @@ class DirParams(ctypes.Structure):
                 + [("src", vp), ("dst", vp)])
 
 
+class ConvUpdateParams(ctypes.Structure):
+    _fields_ = ([(n, i32) for n in ("batch", "dim", "width", "itype", "wtype", "silu_activation")]
+                + [(n, i64) for n in ("x_batch_stride", "x_c_stride", "state_batch_stride", "state_c_stride",
+                                      "state_w_stride", "weight_c_stride", "weight_width_stride",
+                                      "out_batch_stride", "out_c_stride")]
+                + [(n, vp) for n in ("x", "conv_state", "weight", "bias", "out")])
+
+
+class StateUpdateParams(ctypes.Structure):
+    _fields_ = ([(n, i32) for n in ("batch", "dim", "dstate", "itype", "stype", "dt_softplus")]
+                + [(n, i64) for n in ("state_batch_stride", "state_d_stride", "state_n_stride", "x_batch_stride",
+                                      "x_d_stride", "dt_batch_stride", "dt_d_stride", "A_d_stride", "A_n_stride",
+                                      "B_batch_stride", "B_n_stride", "C_batch_stride", "C_n_stride",
+                                      "z_batch_stride", "z_d_stride", "out_batch_stride", "out_d_stride")]
+                + [(n, vp) for n in ("state", "x", "dt", "A", "B", "C", "D", "z", "dt_bias", "out")])
+
+
 EXPORTS = ("vivim_abi_version", "vivim_last_error", "vivim_scan_chunk_len", "vivim_sizeof",
            "vivim_scan_bwd_workspace_bytes", "vivim_scan_fwd_workspace_bytes", "vivim_set_tuning",
            "vivim_selective_scan_fwd", "vivim_selective_scan_bwd",
            "vivim_causal_conv1d_fwd", "vivim_causal_conv1d_bwd", "vivim_dwconv_fwd", "vivim_dwconv_wgrad",
-           "vivim_dir_scatter", "vivim_dir_gather")
+           "vivim_dir_scatter", "vivim_dir_gather", "vivim_causal_conv1d_update", "vivim_selective_state_update")
 
 _lib = None
 
@@ -124,14 +141,16 @@ def lib():
         for name, st in (("vivim_selective_scan_fwd", SsmFwdParams), ("vivim_selective_scan_bwd", SsmBwdParams),
                          ("vivim_causal_conv1d_fwd", ConvFwdParams), ("vivim_causal_conv1d_bwd", ConvBwdParams),
                          ("vivim_dwconv_fwd", DwConvParams), ("vivim_dwconv_wgrad", DwConvWgradParams),
-                         ("vivim_dir_scatter", DirParams), ("vivim_dir_gather", DirParams)):
+                         ("vivim_dir_scatter", DirParams), ("vivim_dir_gather", DirParams),
+                         ("vivim_causal_conv1d_update", ConvUpdateParams),
+                         ("vivim_selective_state_update", StateUpdateParams)):
             fn = getattr(L, name)
             fn.argtypes = [ctypes.POINTER(st), vp]
             fn.restype = ctypes.c_int
-        if L.vivim_abi_version() != 4:
+        if L.vivim_abi_version() != 5:
             raise ImportError("libvivim_hip.so ABI version mismatch")
         for which, st in enumerate((SsmFwdParams, SsmBwdParams, ConvFwdParams, ConvBwdParams, DwConvParams,
-                                    DwConvWgradParams, DirParams)):
+                                    DwConvWgradParams, DirParams, ConvUpdateParams, StateUpdateParams)):
             if L.vivim_sizeof(which) != ctypes.sizeof(st):
                 raise ImportError(f"struct layout mismatch for {st.__name__}: "
                                   f"C {L.vivim_sizeof(which)} vs ctypes {ctypes.sizeof(st)}")
@@ -157,6 +176,8 @@ def algorithmic_bytes(name, P):
         n_act = 5 + (3 if has_z else 0) + (1 if (has_z and f.out_z) else 0)   # u, delta, dout, du, ddelta (+ z, out, dz) (+ out_z)
         return (n_act * act + 2 * bc * (s if f.is_variable_B else 4) + 2 * bc * 4
                 + 4 * (2 * f.dim * f.dstate + 4 * f.dim))
+    if name.endswith("_update"):
+        return 0                                                       # latency-bound single-token steps: not profiled
     if name.startswith("vivim_dir"):
         return 4 * P.batch * P.channels * P.seqlen * _ISIZE[P.itype]  # one flat tensor + three stacked copies
     if name.startswith("vivim_dwconv"):

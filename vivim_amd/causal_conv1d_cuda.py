@@ -1,7 +1,7 @@
 """Drop-in for the reference's `causal_conv1d_cuda` extension module (pybind surface at
 causal-conv1d/csrc/causal_conv1d.cpp:329-333): `causal_conv1d_fwd` / `causal_conv1d_bwd` with the same
 positional signatures, checks and returns, on the gfx950 kernels behind include/vivim_hip.h.
-`causal_conv1d_update` (single-token decode, unused by Vivim) is not built and says so.
+`causal_conv1d_update` (single-token step for streaming inference; not on Vivim's training path) is built too.
 """
 import torch
 
@@ -91,5 +91,30 @@ def causal_conv1d_bwd(x, weight, bias_, dout, dx_, silu_activation):
 
 
 def causal_conv1d_update(x, conv_state, weight, bias_, silu_activation):
-    raise NotImplementedError("causal_conv1d_update (autoregressive decode, causal_conv1d_update.cu:26-86) "
-                              "is outside Vivim's path and is not built yet")
+    """-> out (batch, dim); conv_state (batch, dim, width) is advanced in place (causal_conv1d.cpp:270-327)."""
+    _check(x.dtype in _DT, "causal_conv1d_update not implemented for input type '%s'" % x.dtype)
+    _check(weight.dtype in _DT, "causal_conv1d_update not implemented for weight type '%s'" % weight.dtype)
+    _check(conv_state.dtype == x.dtype, "conv_state must have the dtype of x")
+    _check(x.is_cuda and conv_state.is_cuda and weight.is_cuda, "x, conv_state and weight must be CUDA/HIP tensors")
+    _check(x.dim() == 2 and weight.dim() == 2, "x must be (batch, dim) and weight (dim, width)")
+    batch, dim = x.shape
+    width = weight.shape[-1]
+    _check(tuple(conv_state.shape) == (batch, dim, width), "conv_state must have shape (batch, dim, width)")
+    _check(tuple(weight.shape) == (dim, width), "weight must have shape (dim, width)")
+    _check(2 <= width <= 4, "causal_conv1d only supports width between 2 and 4")
+    if bias_ is not None:
+        _check(bias_.dtype == weight.dtype and bias_.is_cuda and bias_.stride(-1) == 1
+               and tuple(bias_.shape) == (dim,), "bias must be a contiguous (dim,) tensor of weight's dtype")
+    out = torch.empty_like(x)
+    P = _lib.ConvUpdateParams()
+    P.batch, P.dim, P.width = batch, dim, width
+    P.itype, P.wtype, P.silu_activation = _DT[x.dtype], _DT[weight.dtype], int(bool(silu_activation))
+    P.x_batch_stride, P.x_c_stride = x.stride()
+    P.state_batch_stride, P.state_c_stride, P.state_w_stride = conv_state.stride()
+    P.weight_c_stride, P.weight_width_stride = weight.stride()
+    P.out_batch_stride, P.out_c_stride = out.stride()
+    P.x, P.conv_state, P.weight, P.out = x.data_ptr(), conv_state.data_ptr(), weight.data_ptr(), out.data_ptr()
+    P.bias = None if bias_ is None else bias_.data_ptr()
+    with torch.cuda.device(x.device):
+        _lib.call("vivim_causal_conv1d_update", P, torch.cuda.current_stream().cuda_stream)
+    return out

@@ -35,6 +35,8 @@ def causal_conv1d_fn(x, weight, bias=None, activation=None):
 
 
 def causal_conv1d_update(x, conv_state, weight, bias=None, activation=None):
+    """x (batch, dim), conv_state (batch, dim, width) advanced in place, weight (dim, width), bias (dim,)
+    -> out (batch, dim)   (causal_conv1d_interface.py:68-80)."""
     if activation not in _ACTIVATIONS:
         raise NotImplementedError("activation must be None, silu, or swish")
     return causal_conv1d_cuda.causal_conv1d_update(x, conv_state, weight, bias, activation is not None)

@@ -13,6 +13,8 @@ bool ssm_fwd_dispatch(const vivim_ssm_fwd_params&, hipStream_t);
 bool dwconv_fwd_dispatch(const vivim_dwconv_params&, hipStream_t);
 bool dwconv_wgrad_dispatch(const vivim_dwconv_wgrad_params&, hipStream_t);
 template <bool GATHER> bool dir_dispatch(const vivim_dir_params&, hipStream_t);     // dirmap.hip
+void conv_update_launch(const vivim_conv_update_params&, hipStream_t);               // update.hip
+void state_update_launch(const vivim_state_update_params&, hipStream_t);
 bool ssm_bwd_dispatch(const vivim_ssm_bwd_params&, hipStream_t);
 int scan_chunk_len(int itype);
 size_t scan_bwd_workspace_bytes(const vivim_ssm_fwd_params&);
@@ -104,6 +106,8 @@ size_t vivim_sizeof(int which) {
         case 4: return sizeof(vivim_dwconv_params);
         case 5: return sizeof(vivim_dwconv_wgrad_params);
         case 6: return sizeof(vivim_dir_params);
+        case 7: return sizeof(vivim_conv_update_params);
+        case 8: return sizeof(vivim_state_update_params);
     }
     return 0;
 }
@@ -220,6 +224,26 @@ int vivim_dir_gather(const vivim_dir_params* p, void* stream) {
     if (int rc = check_dir(p)) return rc;
     if (!vivim::dir_dispatch<true>(*p, static_cast<hipStream_t>(stream))) return fail(VIVIM_ERR_UNSUPPORTED, "dir_gather: bad itype");
     return after_launch("dir_gather");
+}
+
+int vivim_causal_conv1d_update(const vivim_conv_update_params* p, void* stream) {
+    VCHECK(p != nullptr);
+    VCHECK(dtype_ok(p->itype) && dtype_ok(p->wtype));
+    VCHECK(p->batch > 0 && p->dim > 0 && p->batch <= 65535);
+    if (p->width < 2 || p->width > 4)
+        return fail(VIVIM_ERR_UNSUPPORTED, "causal_conv1d only supports width between 2 and 4");   // causal_conv1d.cpp:295
+    VCHECK(p->x && p->conv_state && p->weight && p->out);
+    vivim::conv_update_launch(*p, static_cast<hipStream_t>(stream));
+    return after_launch("causal_conv1d_update");
+}
+
+int vivim_selective_state_update(const vivim_state_update_params* p, void* stream) {
+    VCHECK(p != nullptr);
+    VCHECK(dtype_ok(p->itype) && (p->stype == VIVIM_F32 || p->stype == p->itype));
+    VCHECK(p->batch > 0 && p->dim > 0 && p->dstate > 0 && p->batch <= 65535);
+    VCHECK(p->state && p->x && p->dt && p->A && p->B && p->C && p->out);
+    vivim::state_update_launch(*p, static_cast<hipStream_t>(stream));
+    return after_launch("selective_state_update");
 }
 
 }  // extern "C"
