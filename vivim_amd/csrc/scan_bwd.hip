@@ -272,10 +272,21 @@ struct BwdSeg {
     float* gin;                // [batch][dim][S][dstate]  g flowing into the segment from the right
 };
 
-// MODE 0: the backward of one segment.  MODE 1: reverse aggregates of one segment only (pre-pass).
-template <typename T, int K, bool HAS_Z, int MINW, int MODE>
+// Packed fp32 pairs: the two channels a wave owns run the same instruction stream, so every element-wise step of
+// the per-state loop is written on float2 = (channel 0, channel 1) and compiles to v_pk_mul/fma/add_f32 -- two
+// channels per VALU issue (the unpacked build issued 105 scalar mul/fma per state and packed 18).
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 exp2_2(f2 v) { return f2{fast_exp2(v.x), fast_exp2(v.y)}; }
+template <int CTRL> __device__ __forceinline__ f2 dpp_mov2(f2 old, f2 src) {
+    return f2{dpp_mov<CTRL>(old.x, src.x), dpp_mov<CTRL>(old.y, src.y)};
+}
+
+// The backward of one segment of the token axis (the whole sequence when S == 1).
+template <typename T, int K, bool HAS_Z, int MINW>
 __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const vivim_ssm_bwd_params p, const BwdSeg sg) {
     constexpr int R = kBwR;
+    static_assert(R == 2, "the state loop is written on channel pairs");
     constexpr int TILE = kWave * K;
     static_assert(TILE == kChunk, "one checkpoint row per step");
     static_assert(2 * TILE == kBwW * kWave, "one thread per (token, dB|dC) element of a step");
@@ -294,15 +305,17 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
     const int d0 = g * cpg + min(pair, ppg - 1) * R;
     const int nvalid = min(R, (g + 1) * cpg - d0);
     const int nsteps = (L + TILE - 1) / TILE;
-    const int seg = MODE == 1 ? blockIdx.z + 1 : blockIdx.z;     // the pre-pass skips segment 0
+    const int seg = blockIdx.z;
     const int s_lo = seg * sg.seg_steps, s_hi = min(nsteps, s_lo + sg.seg_steps);
     const int t_next = s_hi * TILE;                   // first token right of the segment
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int SLOT = 2 * K * kWave;                // floats per wave slot: [dB k0..k3 | dC k0..k3][lane]
     float* slots = smem;                               // [parity][wave][2K][64]
-    float* rec = smem + 2 * kBwW * SLOT + wave * (N * R * kRec);   // [n][r][kRec] wave-private records
-    enum { HCK = 0, GCAR = 1, AFIRST = 2, AVAL = 3, A2VAL = 4, DAACC = 5 };
+    // wave-private records, [state][field][channel]: the pair of a field is one 8-byte read
+    float* rec = smem + 2 * kBwW * SLOT + wave * (N * R * kRec);
+    enum { HCK = 0, GCAR = 1, AFIRST = 2, A2VAL = 3, DAACC = 4 };
+#define VIVIM_REC(n, F, r) rec[((n) * kRec + (F)) * R + (r)]
 
     int d[R];
     float Dv[R], bias[R], msk[R], dD_acc[R], dbias_acc[R];
@@ -328,14 +341,12 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
     for (int i = lane; i < N * R; i += kWave) {
         const int n = i / R, r = i - n * R;
         const float a = A[d[r] * f.A_d_stride + n * f.A_dstate_stride];
-        float* q = rec + i * kRec;
         // shadow slots (odd channel count, surplus waves) get no inflow either: with dy == 0 their g stays 0
-        q[GCAR] = (MODE == 0 && sg.S > 1 && active && r < nvalid)
-                      ? sg.gin[(((int64_t)b * f.dim + d[r]) * sg.S + seg) * N + n] : 0.0f;
-        q[AFIRST] = fast_exp2((r == 0 ? dl_nx[0] : dl_nx[1]) * a * kLog2e);   // exp2(0) = 1 past the end
-        q[AVAL] = a;
-        q[A2VAL] = a * kLog2e;
-        q[DAACC] = 0.0f;
+        VIVIM_REC(n, GCAR, r) = (sg.S > 1 && active && r < nvalid)
+                                    ? sg.gin[(((int64_t)b * f.dim + d[r]) * sg.S + seg) * N + n] : 0.0f;
+        VIVIM_REC(n, AFIRST, r) = fast_exp2((r == 0 ? dl_nx[0] : dl_nx[1]) * a * kLog2e);   // exp2(0) = 1 past the end
+        VIVIM_REC(n, A2VAL, r) = a * kLog2e;
+        VIVIM_REC(n, DAACC, r) = 0.0f;
     }
     wave_lds_fence();
     // the (token, dB|dC) element this thread reduces after every state
@@ -353,28 +364,26 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
     float* __restrict__ dCg = static_cast<float*>(p.dC) + b * p.dC_batch_stride + g * p.dC_group_stride;
     const float* __restrict__ xck = static_cast<const float*>(f.x);
 
-    float dtot[R] = {0.0f, 0.0f}, dfirst[R] = {0.0f, 0.0f};
     for (int step = s_hi - 1; step >= s_lo; --step) {
         const int t0 = step * TILE + lane * K;
         const bool in = t0 < L;                         // host guarantees L % K == 0: all-in or all-out
         VIVIM_STAMP(nsteps - 1 - step, 0, wave, lane);
         // forward checkpoints entering this step, one float per (state, channel)
-        if (MODE == 0)
         for (int i = lane; i < N * R; i += kWave) {
             const int n = i / R, r = i - n * R;
-            rec[i * kRec + HCK] = step > 0 ? xck[(((int64_t)b * f.dim + d[r]) * nsteps + (step - 1)) * N + n] : 0.0f;
+            VIVIM_REC(n, HCK, r) = step > 0 ? xck[(((int64_t)b * f.dim + d[r]) * nsteps + (step - 1)) * N + n] : 0.0f;
         }
-        float dl[R][K], w[R][K], dy[R][K], S1[R][K], S2[R][K], dsum[R];
+        f2 dl[K], w[K], dy[K], S1[K], S2[K], dsum = {0.0f, 0.0f};
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             float df[K], dof[K], uu[K];                 // u is re-read for ddelta at the end of the step: 8 VGPRs less
-            unpack(load_vec<T, K>(uB + d[r] * f.u_d_stride + t0, in && MODE == 0), uu);
+            unpack(load_vec<T, K>(uB + d[r] * f.u_d_stride + t0, in), uu);
             unpack(load_vec<T, K>(dlB + d[r] * f.delta_d_stride + t0, in), df);
             unpack(load_vec<T, K>(doB + d[r] * p.dout_d_stride + t0, in), dof);
             if (HAS_Z) {
                 float zf[K], of[K], dzv[K];
                 unpack(load_vec<T, K>(zB + d[r] * f.z_d_stride + t0, in), zf);
-                unpack(load_vec<T, K>(oB + d[r] * f.out_d_stride + t0, in && MODE == 0), of);
+                unpack(load_vec<T, K>(oB + d[r] * f.out_d_stride + t0, in), of);
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     const float sg = sigmoidf_fast(zf[k]);
@@ -382,33 +391,28 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
                     dof[k] *= zf[k] * sg;
                 }
                 // shadow slots write the same values to the same place as the slot they shadow: harmless
-                if (MODE == 0)
                 store_vec<T, K>(static_cast<T*>(p.dz) + b * p.dz_batch_stride + d[r] * p.dz_d_stride + t0, in && active, dzv);
-                if (MODE == 0 && f.out_z) {                                                        // bwd_kernel.cuh:193-204
+                if (f.out_z) {                                                        // bwd_kernel.cuh:193-204
                     float oz[K];
 #pragma unroll
                     for (int k = 0; k < K; ++k) oz[k] = of[k] * zf[k] * sigmoidf_fast(zf[k]);
                     store_vec<T, K>(static_cast<T*>(f.out_z) + b * f.out_z_batch_stride + d[r] * f.out_z_d_stride + t0, in && active, oz);
                 }
             }
-            dsum[r] = 0.0f;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const float raw = df[k] + bias[r];
                 const float sp = f.delta_softplus ? softplus_ref(raw) : raw;
-                dl[r][k] = in ? sp : 0.0f;              // padded tokens: identity maps both ways
-                dsum[r] += dl[r][k];
-                w[r][k] = dl[r][k] * uu[k];
-                dy[r][k] = dof[k] * msk[r];            // shadow slots / surplus waves: g == 0, dB = dC = dA = 0
-                S1[r][k] = 0.0f;
-                S2[r][k] = 0.0f;
+                const float dlv = in ? sp : 0.0f;       // padded tokens: identity maps both ways
+                dl[k][r] = dlv;
+                dsum[r] += dlv;
+                w[k][r] = dlv * uu[k];
+                dy[k][r] = dof[k] * msk[r];            // shadow slots / surplus waves: g == 0, dB = dC = dA = 0
                 dD_acc[r] = fmaf(dof[k], uu[k], dD_acc[r]);
             }
-            if (MODE == 1) {
-                dtot[r] += dsum[r];
-                dfirst[r] = read_lane(dl[r][0], 0);
-            }
         }
+#pragma unroll
+        for (int k = 0; k < K; ++k) { S1[k] = f2{0.0f, 0.0f}; S2[k] = f2{0.0f, 0.0f}; }
         wave_lds_fence();
         VIVIM_STAMP(nsteps - 1 - step, 1, wave, lane);
         {
@@ -419,95 +423,89 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
                 float Bn[K], Cn[K];
                 unpack(Braw, Bn);
                 unpack(Craw, Cn);
-                {   // next state's rows fly during this state (always issued, so vmcnt stays countable)
+                {   // next state's rows fly during this state (always issued, so vmcnt stays countable); two states
+                    // ahead measured the same
                     const bool nx = in && (n + 1 < N);
                     Braw = load_vec_always<T, K>(Bv + (n + 1) * f.B_dstate_stride + t0, nx, Bv);
                     Craw = load_vec_always<T, K>(Cv + (n + 1) * f.C_dstate_stride + t0, nx, Cv);
                 }
-                if (n == 1) VIVIM_STAMP(nsteps - 1 - step, 11, wave, lane);
-                float q[R][kRec];                      // HCK, GCAR, AFIRST, (AVAL), A2VAL: one 16-byte read + one float
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) q[r][j] = rec[(n * R + r) * kRec + j];
-                    q[r][A2VAL] = rec[(n * R + r) * kRec + A2VAL];
-                }
-                if (n == 1) VIVIM_STAMP(nsteps - 1 - step, 12, wave, lane);
+                if (n == 1) VIVIM_STAMP(nsteps - 1 - step, 2, wave, lane);
+                // the state's record: checkpoint, g carry, first decay of the step to the right, A * log2e (pairs)
+                const f2* q2 = reinterpret_cast<const f2*>(rec + n * kRec * R);
+                const f2 hck = q2[HCK], gcar = q2[GCAR], afirst = q2[AFIRST], a2v = q2[A2VAL];
                 // ---- forward re-scan ----
-                float a[R][K], hs[R][K], P[R], H[R];
+                f2 a[K], hs[K], wB[K];
+                f2 P = exp2_2(dsum * a2v), H = {0.0f, 0.0f};
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    P[r] = fast_exp2(dsum[r] * q[r][A2VAL]);
-                    H[r] = 0.0f;
+                for (int k = 0; k < K; ++k) {
+                    a[k] = exp2_2(dl[k] * a2v);
+                    wB[k] = w[k] * Bn[k];
+                    H = fma2(a[k], H, wB[k]);
+                }
+                if (n == 1) VIVIM_STAMP(nsteps - 1 - step, 3, wave, lane);
+                {
+                    float P0 = P.x, H0 = H.x, P1 = P.y, H1 = H.y;
+                    wave_scan2_affine_fwd(P0, H0, P1, H1);
+                    P = f2{P0, P1};
+                    H = f2{H0, H1};
+                }
+                {
+                    const f2 hend = fma2(P, hck, H);
+                    f2 h = dpp_mov2<kDppWaveShr1>(hck, hend);                // state entering this lane
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
-                        a[r][k] = fast_exp2(dl[r][k] * q[r][A2VAL]);
-                        H[r] = fmaf(a[r][k], H[r], w[r][k] * Bn[k]);
-                        hs[r][k] = 0.0f;
+                        h = fma2(a[k], h, wB[k]);
+                        hs[k] = h;
                     }
                 }
-                if (MODE == 0) {
-                    wave_scan2_affine_fwd(P[0], H[0], P[1], H[1]);
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const float hend = fmaf(P[r], q[r][HCK], H[r]);
-                        float h = dpp_mov<kDppWaveShr1>(q[r][HCK], hend);    // state entering this lane
-#pragma unroll
-                        for (int k = 0; k < K; ++k) {
-                            h = fmaf(a[r][k], h, w[r][k] * Bn[k]);
-                            hs[r][k] = h;
-                        }
-                    }
-                }
-                if (n == 1) VIVIM_STAMP(nsteps - 1 - step, 13, wave, lane);
+                if (n == 1) VIVIM_STAMP(nsteps - 1 - step, 4, wave, lane);
                 // ---- reverse scan of g_t = a_{t+1} g_{t+1} + C_t dy_t ----
-                float an[R], Pr[R], G[R];
+                const f2 an = dpp_mov2<kDppWaveShl1>(afirst, a[0]);          // decay of the token right of this lane
+                f2 cdy[K], Pr = an, G = {0.0f, 0.0f};
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    an[r] = dpp_mov<kDppWaveShl1>(q[r][AFIRST], a[r][0]);    // decay of the token right of this lane
-                    Pr[r] = an[r];
-                    G[r] = 0.0f;
-#pragma unroll
-                    for (int k = K - 1; k >= 0; --k) {
-                        const float al = k == K - 1 ? an[r] : a[r][k + 1];
-                        G[r] = fmaf(al, G[r], Cn[k] * dy[r][k]);
-                        if (k < K - 1) Pr[r] *= al;
-                    }
+                for (int k = K - 1; k >= 0; --k) {
+                    const f2 al = k == K - 1 ? an : a[k + 1];
+                    cdy[k] = dy[k] * Cn[k];
+                    G = fma2(al, G, cdy[k]);
+                    if (k < K - 1) Pr *= al;
                 }
-                wave_scan2_affine_rev_rows(Pr[0], G[0], Pr[1], G[1]);
+                f2 gfirst;
+                {
+                    float P0 = Pr.x, G0 = G.x, P1 = Pr.y, G1 = G.y;
+                    wave_scan2_affine_rev_rows(P0, G0, P1, G1);
+                    wave_scan_rev_join(P0, G0, lane);
+                    wave_scan_rev_join(P1, G1, lane);
+                    gfirst = fma2(f2{P0, P1}, gcar, f2{G0, G1});             // g at this lane's first token
+                }
+                if (n == 1) VIVIM_STAMP(nsteps - 1 - step, 5, wave, lane);
+                f2 gc = dpp_mov2<kDppWaveShl1>(gcar, gfirst);                // g at the token right of this lane
+                f2 dA_part = {0.0f, 0.0f};
                 float dBv[K], dCv[K];
 #pragma unroll
-                for (int k = 0; k < K; ++k) { dBv[k] = 0.0f; dCv[k] = 0.0f; }
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    wave_scan_rev_join(Pr[r], G[r], lane);
-                    const float gfirst = fmaf(Pr[r], q[r][GCAR], G[r]);      // g at this lane's first token
-                    float gc = dpp_mov<kDppWaveShl1>(q[r][GCAR], gfirst);    // g at the token right of this lane
-                    float dA_part = 0.0f;
-                    if (MODE == 0)
-#pragma unroll
-                    for (int k = K - 1; k >= 0; --k) {
-                        const float al = k == K - 1 ? an[r] : a[r][k + 1];
-                        gc = fmaf(al, gc, Cn[k] * dy[r][k]);                 // g_t
-                        const float ahp = hs[r][k] - w[r][k] * Bn[k];        // a_t h_{t-1}
-                        const float t = gc * ahp;
-                        S1[r][k] = fmaf(gc, Bn[k], S1[r][k]);                // du = D dy + d * S1
-                        S2[r][k] = fmaf(t, q[r][A2VAL], S2[r][k]);           // dd = u * S1 + ln2 * S2
-                        dA_part = fmaf(t, dl[r][k], dA_part);
-                        dBv[k] = fmaf(gc, w[r][k], dBv[k]);                  // shadow slots: dy == 0, so gc == 0
-                        dCv[k] = fmaf(dy[r][k], hs[r][k], dCv[k]);
-                    }
-                    const float dA_tot = MODE == 0 ? read_lane(wave_sum_dpp_to63(dA_part), 63) : 0.0f;
-                    const float g0 = read_lane(gfirst, 0), a0 = read_lane(a[r][0], 0);
+                for (int k = K - 1; k >= 0; --k) {
+                    const f2 al = k == K - 1 ? an : a[k + 1];
+                    gc = fma2(al, gc, cdy[k]);                               // g_t
+                    const f2 t = gc * (hs[k] - wB[k]);                       // g_t * a_t h_{t-1}
+                    S1[k] = fma2(gc, f2{Bn[k], Bn[k]}, S1[k]);               // du = D dy + d * S1
+                    S2[k] = fma2(t, a2v, S2[k]);                             // dd = u * S1 + ln2 * S2
+                    dA_part = fma2(t, dl[k], dA_part);
+                    const f2 db = gc * w[k], dc = dy[k] * hs[k];             // shadow slots: dy == 0, so gc == 0
+                    dBv[k] = db.x + db.y;                                    // the pair's sum
+                    dCv[k] = dc.x + dc.y;
+                }
+                if (n == 1) VIVIM_STAMP(nsteps - 1 - step, 6, wave, lane);
+                {
+                    const float dA0 = read_lane(wave_sum_dpp_to63(dA_part.x), 63);
+                    const float dA1 = read_lane(wave_sum_dpp_to63(dA_part.y), 63);
+                    const float g00 = read_lane(gfirst.x, 0), g01 = read_lane(gfirst.y, 0);
+                    const float a00 = read_lane(a[0].x, 0), a01 = read_lane(a[0].y, 0);
                     if (lane == 0) {
-                        float* qq = rec + (n * R + r) * kRec;
-                        qq[GCAR] = g0;                                       // g at this step's first token
-                        qq[AFIRST] = a0;
-                        qq[DAACC] += dA_tot;
+                        f2* qq = reinterpret_cast<f2*>(rec + n * kRec * R);
+                        qq[GCAR] = f2{g00, g01};                             // g at this step's first token
+                        qq[AFIRST] = f2{a00, a01};
+                        qq[DAACC] += f2{dA0, dA1};
                     }
                 }
-                if (n == 1) VIVIM_STAMP(nsteps - 1 - step, 14, wave, lane);
-                if (MODE == 1) { wave_lds_fence(); continue; }
                 {
                     float* sl = slots + ((n & 1) * kBwW + wave) * SLOT + lane;
 #pragma unroll
@@ -516,7 +514,9 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
                         sl[(K + k) * kWave] = dCv[k];
                     }
                 }
+                if (n == 1) VIVIM_STAMP(nsteps - 1 - step, 7, wave, lane);
                 lds_barrier();
+                if (n == 1) VIVIM_STAMP(nsteps - 1 - step, 8, wave, lane);
                 {   // fixed-order sum over the workgroup's 8 channel pairs, then one fp32 atomic per element
                     const float* sp = slots + (n & 1) * kBwW * SLOT + e_slot;
                     float acc = sp[0];
@@ -528,28 +528,22 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
                     const int t = tq < L ? tq : tq % L;
                     atomicAdd((e_isC ? dCg + n * p.dC_dstate_stride : dBg + n * p.dB_dstate_stride) + t, acc);
                 }
-                if (n == 1) VIVIM_STAMP(nsteps - 1 - step, 15, wave, lane);
-                if (n < 4) VIVIM_STAMP(nsteps - 1 - step, 2 + n, wave, lane);
+                if (n == 1) VIVIM_STAMP(nsteps - 1 - step, 9, wave, lane);
             }
-            VIVIM_STAMP(nsteps - 1 - step, 6, wave, lane);
-            VIVIM_STAMP(nsteps - 1 - step, 7, wave, lane);
-            VIVIM_STAMP(nsteps - 1 - step, 8, wave, lane);
-            VIVIM_STAMP(nsteps - 1 - step, 9, wave, lane);
         }
+        VIVIM_STAMP(nsteps - 1 - step, 11, wave, lane);
         // ---- per-channel outputs of the step ----
-        if (MODE == 0)
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             float duv[K], ddv[K], uu[K];
             unpack(load_vec<T, K>(uB + d[r] * f.u_d_stride + t0, in), uu);
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                duv[k] = fmaf(dl[r][k], S1[r][k], Dv[r] * dy[r][k]);
-                ddv[k] = fmaf(uu[k], S1[r][k], S2[r][k] * kLn2);         // S2 was accumulated with A * log2e
+                duv[k] = fmaf(dl[k][r], S1[k][r], Dv[r] * dy[k][r]);
+                ddv[k] = fmaf(uu[k], S1[k][r], S2[k][r] * kLn2);         // S2 was accumulated with A * log2e
             }
             if (f.delta_softplus) {                                           // bwd_kernel.cuh:439-452
-                // sigmoid(raw) = 1 - exp(-softplus(raw)); exact for raw > 20 too (softplus = raw there, and
-                // the reference leaves ddelta unscaled: 1 - exp(-20) rounds to 1 in fp32)
+                // sigmoid(raw) is applied for raw <= 20 only (the reference leaves ddelta unscaled above)
                 float df[K];
                 unpack(load_vec<T, K>(dlB + d[r] * f.delta_d_stride + t0, in), df);
 #pragma unroll
@@ -564,23 +558,6 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
             store_vec<T, K>(static_cast<T*>(p.ddelta) + b * p.ddelta_batch_stride + d[r] * p.ddelta_d_stride + t0, in && active, ddv);
         }
         VIVIM_STAMP(nsteps - 1 - step, 10, wave, lane);
-    }
-    if (MODE == 1) {
-        wave_lds_fence();
-        if (active) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const float tot = wave_sum(dtot[r]);                         // sum_{t in seg} delta_t
-                if (lane == 0 && r < nvalid)
-                    sg.dsum[((int64_t)b * f.dim + d[r]) * sg.S + seg] = tot - dfirst[r] + dl_nx[r];
-            }
-            for (int i = lane; i < N * R; i += kWave) {
-                const int n = i / R, r = i - n * R;
-                if (r < nvalid)
-                    sg.agg[(((int64_t)b * f.dim + d0 + r) * sg.S + seg) * N + n] = rec[i * kRec + GCAR];
-            }
-        }
-        return;
     }
     if (active) {
 #pragma unroll
@@ -598,9 +575,10 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
             const int n = i / R, r = i - n * R;
             if (r < nvalid)
                 atomicAdd(static_cast<float*>(p.dA) + (d0 + r) * p.dA_d_stride + n * p.dA_dstate_stride,
-                          rec[i * kRec + DAACC]);
+                          VIVIM_REC(n, DAACC, r));
         }
     }
+#undef VIVIM_REC
 }
 
 // ---- pre-pass of the token-axis split: per (batch, channel, segment >= 1, state) the reverse aggregate ----------
@@ -802,8 +780,8 @@ static void launch_bwd_fast(const vivim_ssm_bwd_params& p, hipStream_t stream) {
         hipLaunchKernelGGL(ssm_bwd_carry_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream, p, sg);
     }
     dim3 grid(bpg * f.n_groups, f.batch, sg.S);
-    if (f.z) hipLaunchKernelGGL((ssm_bwd_fast_kernel<T, K, true, MINW, 0>), grid, block, smem, stream, p, sg);
-    else     hipLaunchKernelGGL((ssm_bwd_fast_kernel<T, K, false, MINW, 0>), grid, block, smem, stream, p, sg);
+    if (f.z) hipLaunchKernelGGL((ssm_bwd_fast_kernel<T, K, true, MINW>), grid, block, smem, stream, p, sg);
+    else     hipLaunchKernelGGL((ssm_bwd_fast_kernel<T, K, false, MINW>), grid, block, smem, stream, p, sg);
 }
 
 template <typename T>
