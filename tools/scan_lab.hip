@@ -10,6 +10,9 @@
 #include "../vivim_amd/csrc/scan_fwd.hip"
 #include "../vivim_amd/csrc/scan_bwd.hip"
 
+namespace vivim { int tuning_fwd_variant() { const char* e = getenv("VIVIM_FWD_VARIANT"); return e ? atoi(e) : 0; }
+                  int tuning_bwd_variant() { return 0; } }
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 int main(int argc, char** argv) {
@@ -101,16 +104,19 @@ int main(int argc, char** argv) {
         CK(hipEventElapsedTime(&ms, e0, e1));
         printf("BWD B=%d D=%d L=%d N=%d: %.1f us per launch (stamped)\n", B, D, L, N, ms * 1e3 / 3);
         CK(hipMemcpy(hs.data(), dbg, nstamp * 8, hipMemcpyDeviceToHost));
-        const char* bn[] = {"loads+prep", "n0", "n1", "n2", "n3", "n4..15", "barrier", "flush", "barrier2", "outputs"};
+        // stamps of ssm_bwd_fast_kernel: 0 step start, 1 loads+softplus done; inside state n = 1: 2 unpack/prefetch,
+        // 3 record + local forward, 4 forward scan + h, 5 reverse local + scan + join, 6 accumulation loop,
+        // 7 dA reduce + record update + slot stores, 8 barrier, 9 slot sum + atomic; 11 all states done, 10 outputs stored
         for (int w = 0; w < vivim::kStampWaves; w += 7) {
             printf("bwd block 0 wave %d:\n", w);
-            for (int st = 1; st < 5; ++st) {
+            for (int st = 1; st < 4; ++st) {
                 const unsigned long long* s = &hs[((0 * vivim::kStampWaves + w) * vivim::kStampSteps + st) * vivim::kStampSlots];
-                printf("  step %d:", st);
-                for (int k = 0; k < 10; ++k) printf(" %s=%lld", bn[k], (long long)(s[k + 1] - s[k]));
-                printf("  total=%lld\n", (long long)(s[10] - s[0]));
-                printf("      inside n=1: unpack+prefetch=%lld rec-read=%lld fwd=%lld rev+outputs=%lld lds-add=%lld\n",
-                       (long long)(s[11] - s[2]), (long long)(s[12] - s[11]), (long long)(s[13] - s[12]), (long long)(s[14] - s[13]), (long long)(s[15] - s[14]));
+                printf("  step %d: loads+prep=%lld  all-states=%lld  outputs=%lld  total=%lld\n", st, (long long)(s[1] - s[0]),
+                       (long long)(s[11] - s[1]), (long long)(s[10] - s[11]), (long long)(s[10] - s[0]));
+                printf("      state 1: rec+local-fwd=%lld fwd-scan+h=%lld rev-local+scan+join=%lld accumulate=%lld "
+                       "dA+rec+slots=%lld barrier=%lld slot-sum+atomic=%lld  (sum %lld)\n",
+                       (long long)(s[3] - s[2]), (long long)(s[4] - s[3]), (long long)(s[5] - s[4]), (long long)(s[6] - s[5]),
+                       (long long)(s[7] - s[6]), (long long)(s[8] - s[7]), (long long)(s[9] - s[8]), (long long)(s[9] - s[2]));
             }
         }
     }

@@ -283,7 +283,9 @@ template <int CTRL> __device__ __forceinline__ f2 dpp_mov2(f2 old, f2 src) {
 }
 
 // The backward of one segment of the token axis (the whole sequence when S == 1).
-template <typename T, int K, bool HAS_Z, int MINW>
+// DA_LDS (N <= 16): dA partial sums stay per lane in LDS and are reduced over the lanes once per segment, instead of
+// one wave reduction per (state, channel) and step.
+template <typename T, int K, bool HAS_Z, int MINW, bool DA_LDS>
 __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const vivim_ssm_bwd_params p, const BwdSeg sg) {
     constexpr int R = kBwR;
     static_assert(R == 2, "the state loop is written on channel pairs");
@@ -311,9 +313,15 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int SLOT = 2 * K * kWave;                // floats per wave slot: [dB k0..k3 | dC k0..k3][lane]
-    float* slots = smem;                               // [parity][wave][2K][64]
+    // slot buffers: double-buffered on the state parity, one workgroup barrier per state (four buffers and a barrier
+    // every second state measured 4-10 % slower: the skew between waves grows with the distance between barriers)
+    constexpr int NBUF = 2;
+    float* slots = smem;                               // [n % NBUF][wave][2K][64]
     // wave-private records, [state][field][channel]: the pair of a field is one 8-byte read
-    float* rec = smem + 2 * kBwW * SLOT + wave * (N * R * kRec);
+    float* rec = smem + NBUF * kBwW * SLOT + wave * (N * R * kRec);
+    f2* dAl = reinterpret_cast<f2*>(smem + NBUF * kBwW * SLOT + kBwW * (N * R * kRec)) + wave * (N * kWave);   // [state][lane]
+    if (DA_LDS)
+        for (int i = lane; i < N * kWave; i += kWave) dAl[i] = f2{0.0f, 0.0f};
     enum { HCK = 0, GCAR = 1, AFIRST = 2, A2VAL = 3, DAACC = 4 };
 #define VIVIM_REC(n, F, r) rec[((n) * kRec + (F)) * R + (r)]
 
@@ -494,20 +502,25 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
                     dCv[k] = dc.x + dc.y;
                 }
                 if (n == 1) VIVIM_STAMP(nsteps - 1 - step, 6, wave, lane);
-                {
+                if (DA_LDS) {
+                    dAl[n * kWave + lane] += dA_part;                        // wave-private: no barrier
+                    if (lane == 0) {                                         // lane 0 already holds both values
+                        f2* qq = reinterpret_cast<f2*>(rec + n * kRec * R);
+                        qq[GCAR] = gfirst;                                   // g at this step's first token
+                        qq[AFIRST] = a[0];
+                    }
+                } else {
                     const float dA0 = read_lane(wave_sum_dpp_to63(dA_part.x), 63);
                     const float dA1 = read_lane(wave_sum_dpp_to63(dA_part.y), 63);
-                    const float g00 = read_lane(gfirst.x, 0), g01 = read_lane(gfirst.y, 0);
-                    const float a00 = read_lane(a[0].x, 0), a01 = read_lane(a[0].y, 0);
                     if (lane == 0) {
                         f2* qq = reinterpret_cast<f2*>(rec + n * kRec * R);
-                        qq[GCAR] = f2{g00, g01};                             // g at this step's first token
-                        qq[AFIRST] = f2{a00, a01};
+                        qq[GCAR] = gfirst;
+                        qq[AFIRST] = a[0];
                         qq[DAACC] += f2{dA0, dA1};
                     }
                 }
                 {
-                    float* sl = slots + ((n & 1) * kBwW + wave) * SLOT + lane;
+                    float* sl = slots + ((n & (NBUF - 1)) * kBwW + wave) * SLOT + lane;
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
                         sl[k * kWave] = dBv[k];
@@ -517,8 +530,10 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
                 if (n == 1) VIVIM_STAMP(nsteps - 1 - step, 7, wave, lane);
                 lds_barrier();
                 if (n == 1) VIVIM_STAMP(nsteps - 1 - step, 8, wave, lane);
-                {   // fixed-order sum over the workgroup's 8 channel pairs, then one fp32 atomic per element
-                    const float* sp = slots + (n & 1) * kBwW * SLOT + e_slot;
+                {
+                    const int m = n;
+                    // fixed-order sum over the workgroup's 8 channel pairs, then one fp32 atomic per element
+                    const float* sp = slots + (m & (NBUF - 1)) * kBwW * SLOT + e_slot;
                     float acc = sp[0];
 #pragma unroll
                     for (int wv = 1; wv < kBwW; ++wv) acc += sp[wv * SLOT];
@@ -526,7 +541,7 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
                     // carry acc == 0 (their dy and delta*u are 0) and are wrapped onto distinct valid tokens.
                     const int tq = step * TILE + e_tok;
                     const int t = tq < L ? tq : tq % L;
-                    atomicAdd((e_isC ? dCg + n * p.dC_dstate_stride : dBg + n * p.dB_dstate_stride) + t, acc);
+                    atomicAdd((e_isC ? dCg + m * p.dC_dstate_stride : dBg + m * p.dB_dstate_stride) + t, acc);
                 }
                 if (n == 1) VIVIM_STAMP(nsteps - 1 - step, 9, wave, lane);
             }
@@ -573,9 +588,14 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
         wave_lds_fence();
         for (int i = lane; i < N * R; i += kWave) {
             const int n = i / R, r = i - n * R;
+            float tot = VIVIM_REC(n, DAACC, r);
+            if (DA_LDS) {                                                     // sum the 64 per-lane partials of (n, r)
+                const float* q = reinterpret_cast<const float*>(dAl + n * kWave) + r;
+                tot = 0.0f;
+                for (int j = 0; j < kWave; ++j) tot += q[j * R];
+            }
             if (r < nvalid)
-                atomicAdd(static_cast<float*>(p.dA) + (d0 + r) * p.dA_d_stride + n * p.dA_dstate_stride,
-                          VIVIM_REC(n, DAACC, r));
+                atomicAdd(static_cast<float*>(p.dA) + (d0 + r) * p.dA_d_stride + n * p.dA_dstate_stride, tot);
         }
     }
 #undef VIVIM_REC
@@ -768,7 +788,14 @@ static void launch_bwd_fast(const vivim_ssm_bwd_params& p, hipStream_t stream) {
         sg.dsum = sg.gin + nbd * f.dstate;
     }
     const dim3 block(kBwW * kWave);
-    const size_t smem = ((size_t)2 * kBwW * 2 * K * kWave + (size_t)kBwW * f.dstate * kBwR * kRec) * sizeof(float);
+    // LDS: 2 slot buffers (32 KB) + records (N * 512 B) + per-lane dA partials when used (N * 4 KB): 104 KB at N = 16 --
+    // one workgroup per CU either way (register-bound already)
+    // per-lane dA partials in LDS pay off once a workgroup walks several steps (grouped stage 0, 6 steps: 724 -> 698 us);
+    // for one or two steps their zero-fill and final reduction cost more than the per-state wave reductions they
+    // replace (stage 3: 74 -> 80 us)
+    const bool da_lds = f.dstate <= 16 && sg.seg_steps >= 2;
+    const size_t smem = ((size_t)2 * kBwW * 2 * K * kWave + (size_t)kBwW * f.dstate * kBwR * kRec +
+                         (da_lds ? (size_t)kBwW * f.dstate * kWave * 2 : 0)) * sizeof(float);
     if (sg.S > 1) {
         const size_t per_wave = (size_t)f.dstate * kBwR * kWave * sizeof(float);            // 8 KB at N = 16, 32 KB at N = 64
         int nw = (int)((size_t)65536 / per_wave);
@@ -780,8 +807,16 @@ static void launch_bwd_fast(const vivim_ssm_bwd_params& p, hipStream_t stream) {
         hipLaunchKernelGGL(ssm_bwd_carry_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream, p, sg);
     }
     dim3 grid(bpg * f.n_groups, f.batch, sg.S);
-    if (f.z) hipLaunchKernelGGL((ssm_bwd_fast_kernel<T, K, true, MINW>), grid, block, smem, stream, p, sg);
-    else     hipLaunchKernelGGL((ssm_bwd_fast_kernel<T, K, false, MINW>), grid, block, smem, stream, p, sg);
+    auto launch = [&](auto kernel) {
+        static size_t allowed = 65536;                  // per kernel instantiation (the lambda is instantiated per type)
+        if (smem > allowed) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            allowed = smem;
+        }
+        hipLaunchKernelGGL(kernel, grid, block, smem, stream, p, sg);
+    };
+    if (f.z) { if (da_lds) launch(ssm_bwd_fast_kernel<T, K, true, MINW, true>); else launch(ssm_bwd_fast_kernel<T, K, true, MINW, false>); }
+    else     { if (da_lds) launch(ssm_bwd_fast_kernel<T, K, false, MINW, true>); else launch(ssm_bwd_fast_kernel<T, K, false, MINW, false>); }
 }
 
 template <typename T>
