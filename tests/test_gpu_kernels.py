@@ -393,10 +393,15 @@ FULL = [  # (config, batch, dim, N, L, dtype): stage-0 shapes of SURVEY.md secti
     ("cfg5_stage0", 1, 256, 64, 32768, torch.bfloat16),
     ("cfg2_stage3", 3, 1024, 16, 320, torch.bfloat16),
 ]
+FULL = [c + (1,) for c in FULL] + [  # the grouped v3 shapes: three directions side by side, n_groups = 3, contiguous rows
+    ("cfg2_stage0_grouped", 3, 384, 16, 20480, torch.bfloat16, 3),
+    ("cfg2_stage3_grouped", 3, 3072, 16, 320, torch.bfloat16, 3),
+    ("cfg3_stage1_grouped", 8, 768, 16, 20480, torch.float32, 3),
+]
 
 
-@pytest.mark.parametrize("cfg,batch,dim,N,L,dtype", FULL)
-def test_scan_full_size_properties(cfg, batch, dim, N, L, dtype, cuda, ops):
+@pytest.mark.parametrize("cfg,batch,dim,N,L,dtype,G", FULL)
+def test_scan_full_size_properties(cfg, batch, dim, N, L, dtype, G, cuda, ops):
     """At full size the CPU oracle is too slow for every channel, so:
       (a) channels are independent given B/C -> the oracle is run on a 6-channel slice of the full-length
           problem and must match those channels of the full GPU result (fwd + per-channel grads);
@@ -406,9 +411,13 @@ def test_scan_full_size_properties(cfg, batch, dim, N, L, dtype, cuda, ops):
           problem by zeroing dout outside the 6-channel slice."""
     ss, _ = ops
     gen = torch.Generator().manual_seed(42)
-    t = _rand_scan(gen, batch, dim, N, L, 1, dtype, cuda, strided=True, init="module")
+    t = _rand_scan(gen, batch, dim, N, L, G, dtype, cuda, strided=G == 1, init="module")
     out, x, out_z = ss.fwd(t["u"], t["delta"], t["A"], t["B"], t["C"], t["D"], t["z"], t["delta_bias"], True)
-    sel = torch.tensor([0, 1, dim // 2, dim // 2 + 1, dim - 2, dim - 1], device=cuda)
+    if G == 1:
+        sel = torch.tensor([0, 1, dim // 2, dim // 2 + 1, dim - 2, dim - 1], device=cuda)
+    else:               # first and last channel of every group, in order: the slice is itself a G-group problem
+        cpg = dim // G
+        sel = torch.tensor([c for g in range(G) for c in (g * cpg, g * cpg + cpg - 1)], device=cuda)
     b0 = batch - 1
     sub = lambda a: a[b0:b0 + 1].index_select(1, sel)
     r_out, r_out_z, r_last = cpu_oracle.selective_scan_fwd(

@@ -290,8 +290,9 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
     constexpr int R = kBwR;
     static_assert(R == 2, "the state loop is written on channel pairs");
     constexpr int TILE = kWave * K;
-    static_assert(TILE == kChunk, "one checkpoint row per step");
-    static_assert(2 * TILE == kBwW * kWave, "one thread per (token, dB|dC) element of a step");
+    static_assert(TILE % kChunk == 0, "a step starts on a checkpoint row");
+    constexpr int EPT = 2 * TILE / (kBwW * kWave);     // (token, dB|dC) elements of a step each thread reduces
+    static_assert(EPT * kBwW * kWave == 2 * TILE, "whole elements per thread");
     const vivim_ssm_fwd_params& f = p.f;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -358,8 +359,7 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
     }
     wave_lds_fence();
     // the (token, dB|dC) element this thread reduces after every state
-    const int e_tok = tid & (TILE - 1), e_isC = tid >> 8;          // 2*TILE == 512 threads
-    const int e_slot = (e_isC * K + (e_tok & (K - 1))) * kWave + (e_tok / K);
+    const int nck = (L + kChunk - 1) / kChunk;                     // checkpoint rows of x (forward kernel's contract)
 
     const T* __restrict__ uB = static_cast<const T*>(f.u) + b * f.u_batch_stride;
     const T* __restrict__ dlB = static_cast<const T*>(f.delta) + b * f.delta_batch_stride;
@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
         // forward checkpoints entering this step, one float per (state, channel)
         for (int i = lane; i < N * R; i += kWave) {
             const int n = i / R, r = i - n * R;
-            VIVIM_REC(n, HCK, r) = step > 0 ? xck[(((int64_t)b * f.dim + d[r]) * nsteps + (step - 1)) * N + n] : 0.0f;
+            VIVIM_REC(n, HCK, r) = step > 0 ? xck[(((int64_t)b * f.dim + d[r]) * nck + (step * (TILE / kChunk) - 1)) * N + n] : 0.0f;
         }
         f2 dl[K], w[K], dy[K], S1[K], S2[K], dsum = {0.0f, 0.0f};
 #pragma unroll
@@ -530,10 +530,13 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
                 if (n == 1) VIVIM_STAMP(nsteps - 1 - step, 7, wave, lane);
                 lds_barrier();
                 if (n == 1) VIVIM_STAMP(nsteps - 1 - step, 8, wave, lane);
-                {
-                    const int m = n;
+#pragma unroll
+                for (int j = 0; j < EPT; ++j) {
                     // fixed-order sum over the workgroup's 8 channel pairs, then one fp32 atomic per element
-                    const float* sp = slots + (m & (NBUF - 1)) * kBwW * SLOT + e_slot;
+                    const int e = tid + j * (kBwW * kWave);
+                    const int e_tok = e & (TILE - 1), e_isC = e / TILE;
+                    const float* sp = slots + (n & (NBUF - 1)) * kBwW * SLOT +
+                                      (e_isC * K + (e_tok & (K - 1))) * kWave + (e_tok / K);
                     float acc = sp[0];
 #pragma unroll
                     for (int wv = 1; wv < kBwW; ++wv) acc += sp[wv * SLOT];
@@ -541,7 +544,7 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
                     // carry acc == 0 (their dy and delta*u are 0) and are wrapped onto distinct valid tokens.
                     const int tq = step * TILE + e_tok;
                     const int t = tq < L ? tq : tq % L;
-                    atomicAdd((e_isC ? dCg + m * p.dC_dstate_stride : dBg + m * p.dB_dstate_stride) + t, acc);
+                    atomicAdd((e_isC ? dCg + n * p.dC_dstate_stride : dBg + n * p.dB_dstate_stride) + t, acc);
                 }
                 if (n == 1) VIVIM_STAMP(nsteps - 1 - step, 9, wave, lane);
             }
@@ -750,9 +753,22 @@ __global__ void ssm_bwd_carry_kernel(const vivim_ssm_bwd_params p, const BwdSeg 
     }
 }
 
-// How the token axis is cut: enough workgroups to give every CU ~4, segments of whole 256-token steps.
+// Tokens per lane of the fast backward.  Most of a state iteration is scan machinery whose cost does not depend on K
+// (DESIGN.md 4.3), so 8 tokens per lane (512-token steps) nearly halve the instructions per state update: measured
+// -4 ... -25 % on Vivim's shapes -- except where the last 512-token step would be mostly empty (L = 1280: three steps,
+// 20 % of the slots idle, +6 % against five full 256-token steps).  fp32 stays at 4 (its per-token registers are twice as
+// wide: 8 would not fit the 256 VGPRs available at two waves per SIMD).  A pure function of (dtype, seqlen): the
+// workspace query and the launch must agree.
+static int bwd_tokens_per_lane(int itype, int seqlen) {
+    if (itype == VIVIM_F32) return 4;
+    const int64_t slots8 = (int64_t)((seqlen + 511) / 512) * 512, slots4 = (int64_t)((seqlen + 255) / 256) * 256;
+    return slots8 * 100 > slots4 * 115 ? 4 : 8;
+}
+
+// How the token axis is cut: enough workgroups to give every CU ~4, segments of whole steps.
 static void bwd_segmentation(const vivim_ssm_fwd_params& f, int& S, int& seg_steps) {
-    const int nsteps = (f.seqlen + kChunk - 1) / kChunk;
+    const int tile = kWave * bwd_tokens_per_lane(f.itype, f.seqlen);
+    const int nsteps = (f.seqlen + tile - 1) / tile;
     const int cpg = f.dim / f.n_groups;
     const int ppg = (cpg + kBwR - 1) / kBwR;
     const int64_t wgs = (int64_t)((ppg + kBwW - 1) / kBwW) * f.n_groups * f.batch;
@@ -778,7 +794,7 @@ static void launch_bwd_fast(const vivim_ssm_bwd_params& p, hipStream_t stream) {
     const int cpg = f.dim / f.n_groups;
     const int ppg = (cpg + kBwR - 1) / kBwR;
     const int bpg = (ppg + kBwW - 1) / kBwW;
-    BwdSeg sg = {1, (f.seqlen + kChunk - 1) / kChunk, nullptr, nullptr, nullptr};
+    BwdSeg sg = {1, (f.seqlen + kWave * K - 1) / (kWave * K), nullptr, nullptr, nullptr};
     const size_t need = scan_bwd_workspace_bytes(f);
     if (need && p.workspace && (size_t)p.workspace_bytes >= need) {
         bwd_segmentation(f, sg.S, sg.seg_steps);
@@ -819,10 +835,9 @@ static void launch_bwd_fast(const vivim_ssm_bwd_params& p, hipStream_t stream) {
     else     { if (da_lds) launch(ssm_bwd_fast_kernel<T, K, false, MINW, true>); else launch(ssm_bwd_fast_kernel<T, K, false, MINW, false>); }
 }
 
-template <typename T>
-static bool try_bwd_fast(const vivim_ssm_bwd_params& p, hipStream_t stream) {
+template <typename T, int K>
+static bool try_bwd_fast_k(const vivim_ssm_bwd_params& p, hipStream_t stream) {
     const vivim_ssm_fwd_params& f = p.f;
-    constexpr int K = 4;
     if (!f.is_variable_B || !f.is_variable_C || f.dstate > 64 || f.x == nullptr) return false;
     if (tuning_bwd_variant() == 3) return false;
     // unconditional K-element vectors: rows aligned to the vector size, seqlen a whole number of lanes
@@ -848,6 +863,12 @@ static bool try_bwd_fast(const vivim_ssm_bwd_params& p, hipStream_t stream) {
     // of this library may use scratch: `make check-scratch` (part of the default build) enforces it.
     launch_bwd_fast<T, K, 2>(p, stream);
     return true;
+}
+
+template <typename T>
+static bool try_bwd_fast(const vivim_ssm_bwd_params& p, hipStream_t stream) {
+    if (sizeof(T) == 2 && bwd_tokens_per_lane(p.f.itype, p.f.seqlen) == 8) return try_bwd_fast_k<T, sizeof(T) == 2 ? 8 : 4>(p, stream);
+    return try_bwd_fast_k<T, 4>(p, stream);
 }
 
 template <typename T, int K, int R>
