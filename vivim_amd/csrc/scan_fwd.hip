@@ -441,7 +441,7 @@ static_assert(kWave * 4 == kChunk, "generic kernel step must equal the checkpoin
 bool try_fwd_chan(const vivim_ssm_fwd_params& p, hipStream_t stream);   // scan_fwd_chan.hip
 
 bool ssm_fwd_dispatch(const vivim_ssm_fwd_params& p, hipStream_t s) {
-    if (try_fwd_chan(p, s)) return true;               // lanes = channels: opt-in (tuning 5), dstate 16, workspace given
+    if (try_fwd_chan(p, s)) return true;               // lanes = channels: long, wide problems (or tuning 5); needs the workspace
     switch (p.itype) {
         case VIVIM_F32: if (!try_fwd_nsplit<float>(p, s)) launch_fwd<float, 4, 2>(p, s); return true;
         case VIVIM_F16: if (!try_fwd_nsplit<f16_t>(p, s)) launch_fwd<f16_t, 4, 2>(p, s); return true;

@@ -395,7 +395,15 @@ static void fwd_chan_segmentation(const vivim_ssm_fwd_params& f, int tt, int& S,
 static bool fwd_chan_eligible(const vivim_ssm_fwd_params& p, bool shape_only = false) {
     if (!p.is_variable_B || !p.is_variable_C || p.dstate != kChN || p.seqlen % 8 != 0) return false;
     if (p.dim % p.n_groups != 0 || (p.dim / p.n_groups) % kWave != 0) return false;   // whole 64-channel blocks per group
-    if (tuning_fwd_variant() != 5) return false;       // opt-in: the n-split kernel is faster at Vivim's sizes
+    // Automatic choice: long rows with enough 64-channel blocks (the grouped v3 stage 0: 336 vs 369 us; cfg 3 grouped
+    // stage 0: 3085 vs 3453 us).  With fewer wave-tokens the kernels are latency-bound and n-split wins (per-direction
+    // stage 0: 154 vs 127 us; L 5120: 176 vs 159 us) -- DESIGN.md 4.7.  Tuning 5 forces it, any other value excludes it.
+    const int tune = tuning_fwd_variant();
+    if (tune != 5) {
+        if (tune != 0) return false;
+        const int64_t wave_tokens = (int64_t)p.batch * (p.dim / kWave) * p.seqlen;
+        if (p.seqlen < 16384 || wave_tokens < 300000) return false;
+    }
     const int64_t epv = p.itype == VIVIM_F32 ? 4 : 8;
     auto al = [&](const void* q) { return shape_only || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     auto st = [&](int64_t e) { return e % epv == 0; };

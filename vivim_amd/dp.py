@@ -8,6 +8,11 @@ import torch
 import torch.distributed as dist
 
 
+# VIVIM_DP_REHEARSE=1: run the whole multi-rank code path (process group on RCCL, DDP buckets and hooks, all-reduced
+# timing, barriers) with a world of ONE rank -- the only way to exercise it on a one-GPU box.
+_REHEARSE = os.environ.get("VIVIM_DP_REHEARSE", "0") == "1"
+
+
 def dist_env():
     """-> (world, rank, local_rank) from the torchrun environment (1, 0, 0 when launched plainly)."""
     return (int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")),
@@ -18,9 +23,12 @@ def init(backend=None, device=None):
     """Initialise the default process group when WORLD_SIZE > 1.  backend defaults to nccl (= RCCL over xGMI
     on ROCm) when a GPU device is given, else gloo."""
     world, rank, local_rank = dist_env()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _REHEARSE) and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if _REHEARSE:
+            for k, v in (("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):
+                os.environ.setdefault(k, v)
         backend = backend or ("nccl" if device is not None and device.type == "cuda" else "gloo")
         kw = {"device_id": device} if backend == "nccl" else {}
         dist.init_process_group(backend, **kw)
@@ -47,7 +55,7 @@ def freeze_unused(model):
 def wrap(model, device=None, bucket_cap_mb=25):
     """DDP with 25 MB buckets in reverse registration order (the stage-3/2 buckets fly while the long stage-0/1
     backward scans still run); identity when the world is 1."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not _REHEARSE):
         return model
     ids = [device.index] if device is not None and device.type == "cuda" else None
     return torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, bucket_cap_mb=bucket_cap_mb,
@@ -61,7 +69,7 @@ def shard_seed(seed, rank):
 
 def max_over_ranks(seconds, device=None):
     """The step time of the job is that of its slowest rank."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not _REHEARSE):
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -69,7 +77,7 @@ def max_over_ranks(seconds, device=None):
 
 
 def barrier(device=None):
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _REHEARSE):
         dist.barrier()
     if device is not None and device.type == "cuda":
         torch.cuda.synchronize(device)
