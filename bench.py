@@ -11,6 +11,8 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      -- the dominant hot-path kernel (largest total time among the four C-ABI kernels), its
                    algorithmic bytes (vivim_amd/_lib.py:algorithmic_bytes) divided by its
                    HIP-event time, both summed over every launch inside the timed region;
+                   `traffic` is the HBM bytes per launch from committed rocprofv3 --pmc passes over this command
+                   (profiles/r*_bench_pmc_traffic.json), null when none is committed;
   cpu_baseline  -- the pure-PyTorch selective_scan_ref port (oracle/ref_torch.py) timed on this host's cores
                    on a bounded sample (N = 1 only).
 Synthetic data, random-init weights (SegFormer-b3 architecture from a local config): there is no network.
@@ -77,6 +79,21 @@ def cpu_baseline(seconds_budget=20.0):
                       f"{best:.2f} s per call = {L / best:.0f} tokens/s on {os.cpu_count()} host cpus"}
 
 
+def pmc_traffic(entry_point):
+    """HBM bytes per launch of a hot-path entry point as measured by rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over
+    this very command (tools/pmc_bench_traffic.py; bench.py cannot run the profiler on itself): the newest committed
+    profiles/r*_bench_pmc_traffic.json, or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        rec = json.load(open(files[-1]))["per_entry_point"][entry_point]
+        return int(rec["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+    except (KeyError, ValueError, OSError):
+        return None, None
+
+
 def main():
     a = parse()
     from vivim_amd import _lib, dp
@@ -131,6 +148,7 @@ def main():
         hot = [k for k in per if "selective_scan" in k or "causal_conv1d" in k]   # the north-star path's kernels
         dom = max(hot, key=lambda k: per[k][1])
         ach = per[dom][0] / per[dom][1] / 1e9
+        traffic, traffic_src = pmc_traffic(dom.replace("vivim_", ""))
         kernels = {k.replace("vivim_", ""): {"launches": v[2], "total_ms": round(v[1] * 1e3, 3),
                                               "avg_us": round(v[1] / v[2] * 1e6, 2),
                                               "alg_GBps": round(v[0] / v[1] / 1e9, 1)} for k, v in per.items()}
@@ -146,7 +164,9 @@ def main():
                        "step_mode": mode},
             "roofline": {"bound": "hbm", "kernel": dom.replace("vivim_", ""), "achieved": round(ach, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-                         "traffic": None, "launches": per[dom][2],
+                         "traffic": traffic, "traffic_unit": "bytes per launch (PMC, separate passes)",
+                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(per[dom][0] / per[dom][2]),
+                         "launches": per[dom][2],
 
                          "avg_launch_us": round(per[dom][1] / per[dom][2] * 1e6, 2)},
             "kernels": kernels,

@@ -51,9 +51,15 @@ def build_model(num_classes=3, device="cuda", mamba_kwargs=None, drop_path_rate=
     return model.to(device)
 
 
-def make_optimizer(model, lr=1e-4, weight_decay=1e-2, capturable=False):
-    return torch.optim.AdamW((p for p in model.parameters() if p.requires_grad), lr=lr, betas=(0.9, 0.999),
-                             weight_decay=weight_decay, capturable=capturable)
+def make_optimizer(model, lr=1e-4, weight_decay=1e-2, capturable=False, fused=None):
+    """AdamW(lr 1e-4, betas (.9, .999), wd 1e-2) as the reference's configure_optimizers (train.py:503-517).  On a GPU
+    the update runs as PyTorch's fused multi-tensor kernel (same arithmetic, one launch per dtype/device group
+    instead of a Python-side foreach chain: the optimizer was ~10 ms of the host-bound 80 ms step)."""
+    params = [p for p in model.parameters() if p.requires_grad]
+    if fused is None:
+        fused = bool(params) and all(p.is_cuda for p in params) and not capturable
+    kw = {"fused": True} if fused else {"capturable": capturable}
+    return torch.optim.AdamW(params, lr=lr, betas=(0.9, 0.999), weight_decay=weight_decay, **kw)
 
 
 def synthetic_batch(batch, clip_length, image_size, num_classes, device, seed):
