@@ -108,3 +108,10 @@ def test_dir_maps_reject_bad_arguments_on_host():
     P.seqlen, P.nframes = 32, 5
     assert L.vivim_dir_scatter(ctypes.byref(P), None) != 0        # seqlen not a multiple of nframes
     assert b"" != L.vivim_last_error()
+
+
+def test_graft_entry_build_is_consistent():
+    """__graft_entry__.build() (what the driver runs every round) must accept the library it has just built: its ABI
+    assertion is derived from the header, not hard-coded."""
+    import __graft_entry__ as g
+    g.build()

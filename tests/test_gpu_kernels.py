@@ -131,6 +131,28 @@ def test_conv_deterministic_outputs(cuda, ops):
         assert torch.allclose(dw, dw0, rtol=1e-4, atol=1e-4) and torch.allclose(db, db0, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_channel_last(dtype, cuda, ops):
+    """x with unit stride along channels (causal_conv1d.cpp:151-152; the reference's test grid has channel_last True,
+    test_causal_conv1d.py:20): same values as the channel-first call, outputs and dx in x's layout."""
+    from causal_conv1d import causal_conv1d_fn
+    g = torch.Generator().manual_seed(21)
+    xc = torch.randn(2, 24, 96, generator=g).to(dtype).to(cuda)
+    xl = xc.transpose(1, 2).contiguous().transpose(1, 2)               # (B, D, L) with strides (D*L, 1, D)
+    assert xl.stride(1) == 1 and xl.stride(2) == 24
+    w, b = torch.randn(24, 4, generator=g).to(cuda), torch.randn(24, generator=g).to(cuda)
+    res = []
+    for x in (xc, xl):
+        x = x.detach().requires_grad_(True)
+        y = causal_conv1d_fn(x, w, b, "silu")
+        (dx,) = torch.autograd.grad(y, x, torch.ones_like(y))
+        res.append((y, dx))
+    assert res[1][0].stride() == xl.stride() and res[1][1].stride() == xl.stride()
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    r = cpu_oracle.causal_conv1d_fwd(xc, w, b, True)
+    assert rel_err(res[1][0].float(), _round(r, dtype)) < _tol(dtype)
+
+
 def test_conv_errors(cuda, ops):
     _, cc = ops
     from causal_conv1d import causal_conv1d_fn

@@ -25,9 +25,6 @@ def _checks(x, weight, bias_):
     width = weight.shape[-1]
     _check(tuple(weight.shape) == (dim, width), "weight must have shape (dim, width)")
     _check(x.stride(2) == 1 or x.stride(1) == 1, "x must have unit stride along seqlen or along channels")
-    if x.stride(1) == 1 and x.stride(2) > 1:
-        raise RuntimeError("causal_conv1d: channel-last layout is not built in this MI355X port "
-                           "(Vivim's x always has unit seqlen stride); pass x.contiguous()")
     _check(2 <= width <= 4, "causal_conv1d only supports width between 2 and 4")
     if bias_ is not None:
         _check(bias_.dtype == weight.dtype and bias_.is_cuda and bias_.stride(-1) == 1
@@ -45,9 +42,20 @@ def _fill(P, x, weight, bias_, silu_activation, dims):
     P.bias = None if bias_ is None else bias_.data_ptr()
 
 
+def _channel_last(x):
+    """(batch, dim, seqlen) with unit stride along channels and not along seqlen (causal_conv1d.cpp:151-152)."""
+    return x.stride(1) == 1 and x.stride(2) > 1
+
+
 def causal_conv1d_fwd(x, weight, bias_, silu_activation):
     """-> out (empty_like(x)); causal_conv1d.cpp:130-189."""
     dims = _checks(x, weight, bias_)
+    if _channel_last(x):
+        # The reference has separate channel-last kernels (causal_conv1d_fwd.cu:193-298).  Vivim never produces this
+        # layout, so it is served by the channel-first kernel on a transposed copy; the result comes back in x's layout.
+        out = torch.empty_like(x)
+        out.copy_(causal_conv1d_fwd(x.contiguous(), weight, bias_, silu_activation))
+        return out
     out = _lib.empty_like(x)
     if out.stride(2) != 1:       # empty_like of an exotic view may not keep unit seqlen stride
         out = _lib.empty(tuple(x.shape), x.dtype, x.device)
@@ -66,6 +74,11 @@ def causal_conv1d_bwd(x, weight, bias_, dout, dx_, silu_activation):
     batch, dim, seqlen, width = dims
     _check(dout.is_cuda and dout.dtype == x.dtype and tuple(dout.shape) == (batch, dim, seqlen),
            "dout must match x")
+    if _channel_last(x):                              # see causal_conv1d_fwd; dx comes back in x's layout
+        dxc, dweight, dbias = causal_conv1d_bwd(x.contiguous(), weight, bias_, dout.contiguous(), None, silu_activation)
+        dx = dx_ if dx_ is not None else torch.empty_like(x)
+        dx.copy_(dxc)
+        return [dx, dweight, dbias]
     if dout.stride(2) != 1:
         dout = dout.contiguous()                      # causal_conv1d.cpp:220
     if dx_ is not None:
