@@ -505,3 +505,67 @@ def test_conv_full_size_properties(cfg, batch, dim, L, dtype, cuda, ops):
         lhs = (lin.double() * g.double()).sum()
         rhs = (x.double() * dx.double()).sum()
         assert abs(float(lhs - rhs)) / abs(float(lhs)) < 1e-5
+
+
+# ------------------------------------------------------------------ randomised cases (hypothesis)
+
+def _hyp():
+    hyp = pytest.importorskip("hypothesis")
+    return hyp, hyp.strategies
+
+
+def test_scan_random_cases_match_oracle(cuda, ops):
+    """Random small problems drawn by hypothesis -- shape, groups, every optional argument, (L, B*L, 1)-strided or
+    contiguous rows, dtype, softplus -- forward and all gradients against the C oracle.  Shapes are small enough that
+    several kernel families and their tails (ragged rows, one-token rows, odd channel counts, N not a multiple of 8)
+    are hit in one run; the seed is fixed so the run is reproducible."""
+    hyp, st = _hyp()
+    ss, _ = ops
+
+    @hyp.settings(max_examples=200, deadline=None, derandomize=True,
+                  suppress_health_check=list(hyp.HealthCheck))
+    @hyp.given(batch=st.integers(1, 3), cpg=st.sampled_from([1, 2, 3, 5, 8, 16, 64]), G=st.sampled_from([1, 1, 2, 3]),
+               N=st.sampled_from([1, 3, 8, 16, 16, 24, 64]),
+               L=st.one_of(st.integers(1, 40), st.sampled_from([64, 248, 256, 264, 512, 520, 1032])),
+               dtype=st.sampled_from([torch.float32, torch.bfloat16, torch.float16]),
+               has_z=st.booleans(), has_D=st.booleans(), has_bias=st.booleans(), softplus=st.booleans(),
+               strided=st.booleans(), seed=st.integers(0, 2 ** 16))
+    def run(batch, cpg, G, N, L, dtype, has_z, has_D, has_bias, softplus, strided, seed):
+        gen = torch.Generator().manual_seed(seed)
+        t = _rand_scan(gen, batch, cpg * G, N, L, G, dtype, cuda, has_z, has_D, has_bias, softplus, strided=strided)
+        _check_scan(t, ss)
+
+    run()
+
+
+def test_conv_random_cases_match_oracle(cuda, ops):
+    """Random conv1d problems (width, bias, activation, row length incl. lengths shorter than the filter, dtype,
+    strided rows) against the C oracle, forward and backward."""
+    hyp, st = _hyp()
+    _, cc = ops
+
+    @hyp.settings(max_examples=60, deadline=None, derandomize=True, suppress_health_check=list(hyp.HealthCheck))
+    @hyp.given(batch=st.integers(1, 3), dim=st.sampled_from([1, 2, 7, 64, 130]), width=st.integers(2, 4),
+               L=st.one_of(st.integers(1, 20), st.sampled_from([255, 256, 257, 1023, 2056])),
+               dtype=st.sampled_from([torch.float32, torch.bfloat16, torch.float16]), has_bias=st.booleans(),
+               silu=st.booleans(), strided=st.booleans(), seed=st.integers(0, 2 ** 16))
+    def run(batch, dim, width, L, dtype, has_bias, silu, strided, seed):
+        g = torch.Generator().manual_seed(seed)
+        mk = lambda: (torch.randn(dim, batch, L, generator=g).to(dtype).to(cuda).transpose(0, 1) if strided
+                      else torch.randn(batch, dim, L, generator=g).to(dtype).to(cuda))
+        x, dout = mk(), mk()
+        w = torch.randn(dim, width, generator=g).to(cuda)
+        b = torch.randn(dim, generator=g).to(cuda) if has_bias else None
+        out = cc.causal_conv1d_fwd(x, w, b, silu)
+        r = cpu_oracle.causal_conv1d_fwd(x, w, b, silu)
+        tol = _tol(dtype)
+        assert rel_err(out.float(), _round(r, dtype)) < tol
+        dx, dw, db = cc.causal_conv1d_bwd(x, w, b, dout, None, silu)
+        rdx, rdw, rdb = cpu_oracle.causal_conv1d_bwd(x, w, b, dout, silu)
+        gt = max(tol, 1e-4) * (4 if dtype != torch.float32 else 1)
+        assert rel_err(dx.float(), _round(rdx, dtype)) < gt
+        assert rel_err(dw.float(), rdw) < gt * 2
+        if has_bias:
+            assert rel_err(db.float(), rdb) < gt * 2
+
+    run()

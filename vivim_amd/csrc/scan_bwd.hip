@@ -398,13 +398,13 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
                     dzv[k] = dof[k] * of[k] * sg * (1.0f + zf[k] * (1.0f - sg));     // bwd_kernel.cuh:186-191
                     dof[k] *= zf[k] * sg;
                 }
-                // shadow slots write the same values to the same place as the slot they shadow: harmless
-                store_vec<T, K>(static_cast<T*>(p.dz) + b * p.dz_batch_stride + d[r] * p.dz_d_stride + t0, in && active, dzv);
+                // shadow slots (r >= nvalid: odd channel count) must not store: their dy is zeroed, so their du / ddelta are 0
+                store_vec<T, K>(static_cast<T*>(p.dz) + b * p.dz_batch_stride + d[r] * p.dz_d_stride + t0, in && active && r < nvalid, dzv);
                 if (f.out_z) {                                                        // bwd_kernel.cuh:193-204
                     float oz[K];
 #pragma unroll
                     for (int k = 0; k < K; ++k) oz[k] = of[k] * zf[k] * sigmoidf_fast(zf[k]);
-                    store_vec<T, K>(static_cast<T*>(f.out_z) + b * f.out_z_batch_stride + d[r] * f.out_z_d_stride + t0, in && active, oz);
+                    store_vec<T, K>(static_cast<T*>(f.out_z) + b * f.out_z_batch_stride + d[r] * f.out_z_d_stride + t0, in && active && r < nvalid, oz);
                 }
             }
 #pragma unroll
@@ -572,8 +572,8 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
             }
 #pragma unroll
             for (int k = 0; k < K; ++k) dbias_acc[r] += in ? ddv[k] : 0.0f;
-            store_vec<T, K>(static_cast<T*>(p.du) + b * p.du_batch_stride + d[r] * p.du_d_stride + t0, in && active, duv);
-            store_vec<T, K>(static_cast<T*>(p.ddelta) + b * p.ddelta_batch_stride + d[r] * p.ddelta_d_stride + t0, in && active, ddv);
+            store_vec<T, K>(static_cast<T*>(p.du) + b * p.du_batch_stride + d[r] * p.du_d_stride + t0, in && active && r < nvalid, duv);
+            store_vec<T, K>(static_cast<T*>(p.ddelta) + b * p.ddelta_batch_stride + d[r] * p.ddelta_d_stride + t0, in && active && r < nvalid, ddv);
         }
         VIVIM_STAMP(nsteps - 1 - step, 10, wave, lane);
     }
