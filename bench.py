@@ -157,11 +157,14 @@ def main():
                                               "avg_us": round(v[1] / v[2] * 1e6, 2),
                                               "alg_GBps": round(v[0] / v[1] / 1e9, 1)} for k, v in per.items()}
         out = {
-            "metric": "frames/sec fwd+bwd, 256x256 clip=5 3-class", "value": round(frames / elapsed, 3),
+            "metric": f"frames/sec fwd+bwd, {a.image_size}x{a.image_size} clip={a.clip_length} {a.num_classes}-class",
+            "value": round(frames / elapsed, 3),
             "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": "Vivim train step (fwd+loss+bwd+AdamW), BASELINE.json configs[1]",
+            "config": {"workload": "Vivim train step (fwd+loss+bwd+AdamW), BASELINE.json configs[1]"
+                       if (a.image_size, a.clip_length, a.train_bs, a.dtype) == (256, 5, 3, "bf16")
+                       else "Vivim train step (fwd+loss+bwd+AdamW), non-default sizes",
                        "image_size": a.image_size, "clip_length": a.clip_length, "num_classes": a.num_classes,
                        "per_gpu_batch": a.train_bs, "global_batch": a.train_bs * world, "d_state": a.d_state,
                        "backbone": "SegFormer-b3 architecture, random init", "parallelism": f"dp{world}",

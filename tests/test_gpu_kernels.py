@@ -132,6 +132,29 @@ def test_conv_deterministic_outputs(cuda, ops):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("seqlen", [151, 1024])
+def test_conv_channel_slice_of_larger_tensor(dtype, seqlen, cuda, ops):
+    """The reference's conv test feeds a channel slice of a larger tensor (test_causal_conv1d.py:39-46: batch 2,
+    dim 4096 + 32 taken out of 4096 + dim + 64 channels): non-trivial batch stride, unaligned row starts for odd seqlen."""
+    _, cc = ops
+    g = torch.Generator().manual_seed(seqlen)
+    dim = 4096 + 32
+    big = torch.randn(2, 4096 + dim + 64, seqlen, generator=g).to(dtype).to(cuda)
+    x = big[:, 4096:4096 + dim, :]
+    assert not x.is_contiguous()
+    w, b = torch.randn(dim, 4, generator=g).to(cuda), torch.randn(dim, generator=g).to(cuda)
+    dout = torch.randn(2, dim, seqlen, generator=g).to(dtype).to(cuda)
+    out = cc.causal_conv1d_fwd(x, w, b, True)
+    tol = _tol(dtype)
+    assert rel_err(out.float(), _round(cpu_oracle.causal_conv1d_fwd(x, w, b, True), dtype)) < tol
+    dx, dw, db = cc.causal_conv1d_bwd(x, w, b, dout, None, True)
+    rdx, rdw, rdb = cpu_oracle.causal_conv1d_bwd(x, w, b, dout, True)
+    gt = max(tol, 1e-4) * (4 if dtype != torch.float32 else 1)
+    assert rel_err(dx.float(), _round(rdx, dtype)) < gt
+    assert rel_err(dw.float(), rdw) < gt * 2 and rel_err(db.float(), rdb) < gt * 2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv_channel_last(dtype, cuda, ops):
     """x with unit stride along channels (causal_conv1d.cpp:151-152; the reference's test grid has channel_last True,
     test_causal_conv1d.py:20): same values as the channel-first call, outputs and dx in x's layout."""

@@ -192,3 +192,33 @@ def test_grouped_module_random_shapes(cuda, monkeypatch):
             assert float((a - b).abs().max()) <= 3e-5 * float(b.abs().max()) + 1e-9
 
     run()
+
+
+def test_fused_inner_op_reference_test_shape(cuda):
+    """The shape of the reference's own test_mamba_inner_fn (tests/ops/test_selective_scan.py:152-249: dim 768,
+    dstate 8, dt_rank 48, seqlen 128, batch 2) against the torch restatement of mamba_inner_ref, forward and every
+    gradient (the reference asserts the forward only and prints the gradient differences)."""
+    from mamba_ssm.ops.selective_scan_interface import mamba_inner_fn_no_out_proj
+    from oracle import ref_torch
+    b, d_inner, n, r, L = 2, 768, 8, 48, 128
+    g = torch.Generator().manual_seed(0)
+    p = dict(conv_w=torch.randn(d_inner, 1, 4, generator=g) * 0.3, conv_b=torch.randn(d_inner, generator=g) * 0.1,
+             x_proj=torch.randn(r + 2 * n, d_inner, generator=g) * d_inner ** -0.5,
+             dt_proj=(torch.rand(d_inner, r, generator=g) * 2 - 1) * r ** -0.5,
+             A=-torch.rand(d_inner, n, generator=g) - 0.1, D=torch.randn(d_inner, generator=g),
+             dt_bias=torch.rand(d_inner, generator=g) - 4.0)
+    xz = torch.randn(b, 2 * d_inner, L, generator=g)
+    dout = torch.randn(b, d_inner, L, generator=g)
+
+    def run(device, fn, **kw):
+        q = {k: v.to(device).requires_grad_(True) for k, v in p.items()}
+        x = xz.to(device).requires_grad_(True)
+        y = fn(x, q["conv_w"], q["conv_b"], q["x_proj"], q["dt_proj"], q["A"], *kw.get("mid", ()), q["D"],
+               delta_bias=q["dt_bias"], delta_softplus=True)
+        y.backward(dout.to(device))
+        return [y.detach().cpu(), x.grad.cpu()] + [q[k].grad.cpu() for k in sorted(q)]
+
+    got = run(cuda, mamba_inner_fn_no_out_proj, mid=(None, None))
+    want = run("cpu", ref_torch.mamba_inner_no_out_proj_ref)
+    for i, (a, w) in enumerate(zip(got, want)):
+        assert rel_err(a, w) < 3e-4, i
