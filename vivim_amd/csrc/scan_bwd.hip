@@ -855,7 +855,8 @@ static bool try_bwd_fast_k(const vivim_ssm_bwd_params& p, hipStream_t stream) {
                 !st(f.out_batch_stride) || !st(f.out_d_stride) || !st(p.dz_batch_stride) || !st(p.dz_d_stride) ||
                 (f.out_z && (!al(f.out_z) || !st(f.out_z_batch_stride) || !st(f.out_z_d_stride)))))
         return false;
-    // MINW = 2: registers uncapped (144-152 VGPRs, one 8-wave workgroup per CU).  The 128-VGPR build (MINW = 4, two
+    // MINW = 2: registers uncapped (144-152 VGPRs at K = 4, 229-240 at K = 8; one 8-wave workgroup per CU, two waves per
+    // SIMD, 256 VGPRs available).  A 128-VGPR build of the K = 4 kernel (MINW = 4, two
     // workgroups per CU) measured ~12% faster but needs 28-48 bytes of scratch per lane, and hipcc (ROCm 7.2) may
     // place such a VGPR spill at the top of the join block of a divergent loop, BEFORE the s_or_b64 that
     // restores EXEC: the store then runs with EXEC = 0, nothing is saved, and the reload returns garbage (seen as
