@@ -63,14 +63,17 @@ __global__ void __launch_bounds__(256) ssm_fwd_bc_kernel(const vivim_ssm_fwd_par
     }
 }
 
-// ---- the half-token state update, hand-scheduled -------------------------------------------------------------
-// 8 states of one token: a = exp2(dl*A2); h = a*h + (w*B); y += h*C  with B, C as SGPR operands.
-// Two FIXED scalar sets ping-pong: X = s[68:83], Y = s[84:99] (one BC half row each: B0-7 | C0-7).  A block
-// first issues the load of the set the NEXT block consumes, computes from its own set, and ends with
-// s_waitcnt lgkmcnt(0): nothing of ours is in flight between blocks, so the compiler's own waits never drain a
-// prefetch early.  The kernel is compiled with amdgpu_num_sgpr(kChSgprLimit): the compiler never allocates
-// s[68:99] itself, so the sets survive the compiler-generated code between the blocks (register allocation kept
-// spilling the scalar sets to VGPR lanes inside the hot loop when this was plain C++).
+// ---- the per-token state update, hand-scheduled ---------------------------------------------------------------
+// 16 states of one token: a = exp2(dl*A2); h = a*h + (w*B); y += h*C  with B, C as SGPR operands.
+// Two FIXED scalar sets ping-pong, each one whole BC row [B0-7 | C0-7 | B8-15 | C8-15]: X = s[68:99], Y = s[36:67].
+// A token is two asm statements (the operand limit is 30): the first issues BOTH loads of the row the NEXT token
+// consumes and computes states 0-7 from its own set, the second computes states 8-15 and ends with
+// s_waitcnt lgkmcnt(0).  Scalar loads return out of order, so every wait on them is lgkmcnt(0): one wait per token, a
+// whole token of work (~90 VALU instructions) between issue and wait.  (The first version waited per HALF token: the
+// SQ counters showed the waves parked 42 % of the time.)  Nothing of ours is in flight between tokens, so the
+// compiler's own waits never drain a prefetch early.  The kernel is compiled with amdgpu_num_sgpr(kChSgprLimit): the
+// compiler never allocates s[36:99] itself, so the sets survive the compiler-generated code between the statements
+// (register allocation kept spilling the scalar sets to VGPR lanes inside the hot loop when this was plain C++).
 #define CH_S4(i0, i1, i2, i3, B0, B1, B2, B3)                                                   \
     "v_mul_f32 %[t0], %[dl], %[a" #i0 "]\n\tv_mul_f32 %[t1], %[dl], %[a" #i1 "]\n\t"            \
     "v_mul_f32 %[t2], %[dl], %[a" #i2 "]\n\tv_mul_f32 %[t3], %[dl], %[a" #i3 "]\n\t"            \
@@ -89,50 +92,77 @@ __global__ void __launch_bounds__(256) ssm_fwd_bc_kernel(const vivim_ssm_fwd_par
       [t2] "=&v"(t2), [t3] "=&v"(t3), [u0] "=&v"(u0), [u1] "=&v"(u1), [u2] "=&v"(u2), [u3] "=&v"(u3)             \
     : [a0] "v"(ap[0]), [a1] "v"(ap[1]), [a2] "v"(ap[2]), [a3] "v"(ap[3]), [a4] "v"(ap[4]), [a5] "v"(ap[5]),      \
       [a6] "v"(ap[6]), [a7] "v"(ap[7]), [dl] "v"(dl), [w] "v"(w), [ptr] "s"(next)
-#define CH_CLOB_X "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83"
-#define CH_CLOB_Y "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
+#define CH_CLOB                                                                                                  \
+    "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",  \
+    "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67",  \
+    "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83",  \
+    "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
 
-constexpr int kChSgprLimit = 64;
+constexpr int kChSgprLimit = 40;   // advisory: the compiler peaks at s39 (tile store phase) whatever is asked below ~48
 
-// cur = X: computes from s[68:83], prefetches `next` into s[84:99]
+// X = s[68:99]: B0-7 s68-75 | C0-7 s76-83 | B8-15 s84-91 | C8-15 s92-99;  Y = s[36:67] likewise.
+// X is the set that is live at block and tile boundaries (the row of the next token to process), where the compiler's
+// own code peaks at s39: it sits high.  Y is only live between the two tokens of a pair inside a block, where the
+// compiler emits no scalar code above s35 -- `make check-chan-sgpr` verifies both statements on the generated ISA.
+// PASS 1 needs B only: two 8-dword loads into the B positions of the set.
+#define CH_LOAD_Y2 "s_load_dwordx16 s[36:51], %[ptr], 0x0\n\ts_load_dwordx16 s[52:67], %[ptr], 0x40\n\t"
+#define CH_LOAD_X2 "s_load_dwordx16 s[68:83], %[ptr], 0x0\n\ts_load_dwordx16 s[84:99], %[ptr], 0x40\n\t"
+#define CH_LOAD_Y1 "s_load_dwordx8 s[36:43], %[ptr], 0x0\n\ts_load_dwordx8 s[52:59], %[ptr], 0x40\n\t"
+#define CH_LOAD_X1 "s_load_dwordx8 s[68:75], %[ptr], 0x0\n\ts_load_dwordx8 s[84:91], %[ptr], 0x40\n\t"
+
+// states 0-7 of the token whose row is in X; issues the loads of `next` (the following token's row) into Y
 template <int PASS>
-__device__ __forceinline__ void chan_half_x(float* hp, const float* ap, float dl, float w, float& y0, float& y1,
-                                            const float* next) {
+__device__ __forceinline__ void chan_lo_x(float* hp, const float* ap, float dl, float w, float& y0, float& y1, const float* next) {
     float t0, t1, t2, t3, u0, u1, u2, u3;
     if (PASS == 2)
-        asm volatile("s_load_dwordx16 s[84:99], %[ptr], 0x0\n\t"
-                     CH_S4(0, 1, 2, 3, s68, s69, s70, s71) CH_S4(4, 5, 6, 7, s72, s73, s74, s75)
-                     CH_Y4(0, 1, 2, 3, s76, s77, s78, s79) CH_Y4(4, 5, 6, 7, s80, s81, s82, s83)
-                     "s_waitcnt lgkmcnt(0)"
-                     CH_OPERANDS(hp, ap) : CH_CLOB_X, CH_CLOB_Y);
+        asm volatile("; CHAN lo_x\n\t" CH_LOAD_Y2 CH_S4(0, 1, 2, 3, s68, s69, s70, s71) CH_S4(4, 5, 6, 7, s72, s73, s74, s75)
+                     CH_Y4(0, 1, 2, 3, s76, s77, s78, s79) CH_Y4(4, 5, 6, 7, s80, s81, s82, s83) "s_nop 0"
+                     CH_OPERANDS(hp, ap) : CH_CLOB);
     else
-        asm volatile("s_load_dwordx8 s[84:91], %[ptr], 0x0\n\t"
-                     CH_S4(0, 1, 2, 3, s68, s69, s70, s71) CH_S4(4, 5, 6, 7, s72, s73, s74, s75)
-                     "s_waitcnt lgkmcnt(0)"
-                     CH_OPERANDS(hp, ap) : CH_CLOB_X, CH_CLOB_Y);
+        asm volatile("; CHAN lo_x\n\t" CH_LOAD_Y1 CH_S4(0, 1, 2, 3, s68, s69, s70, s71) CH_S4(4, 5, 6, 7, s72, s73, s74, s75) "s_nop 0"
+                     CH_OPERANDS(hp, ap) : CH_CLOB);
 }
-// cur = Y: computes from s[84:99], prefetches `next` into s[68:83]
+// states 8-15 of the token whose row is in X; then waits for the loads issued by chan_lo_x
 template <int PASS>
-__device__ __forceinline__ void chan_half_y(float* hp, const float* ap, float dl, float w, float& y0, float& y1,
-                                            const float* next) {
+__device__ __forceinline__ void chan_hi_x(float* hp, const float* ap, float dl, float w, float& y0, float& y1) {
+    float t0, t1, t2, t3, u0, u1, u2, u3;
+    const float* next = nullptr;
+    if (PASS == 2)
+        asm volatile("; CHAN hi_x\n\t" CH_S4(0, 1, 2, 3, s84, s85, s86, s87) CH_S4(4, 5, 6, 7, s88, s89, s90, s91)
+                     CH_Y4(0, 1, 2, 3, s92, s93, s94, s95) CH_Y4(4, 5, 6, 7, s96, s97, s98, s99) "s_waitcnt lgkmcnt(0)"
+                     CH_OPERANDS(hp, ap) : CH_CLOB);
+    else
+        asm volatile("; CHAN hi_x\n\t" CH_S4(0, 1, 2, 3, s84, s85, s86, s87) CH_S4(4, 5, 6, 7, s88, s89, s90, s91) "s_waitcnt lgkmcnt(0)"
+                     CH_OPERANDS(hp, ap) : CH_CLOB);
+}
+template <int PASS>
+__device__ __forceinline__ void chan_lo_y(float* hp, const float* ap, float dl, float w, float& y0, float& y1, const float* next) {
     float t0, t1, t2, t3, u0, u1, u2, u3;
     if (PASS == 2)
-        asm volatile("s_load_dwordx16 s[68:83], %[ptr], 0x0\n\t"
-                     CH_S4(0, 1, 2, 3, s84, s85, s86, s87) CH_S4(4, 5, 6, 7, s88, s89, s90, s91)
-                     CH_Y4(0, 1, 2, 3, s92, s93, s94, s95) CH_Y4(4, 5, 6, 7, s96, s97, s98, s99)
-                     "s_waitcnt lgkmcnt(0)"
-                     CH_OPERANDS(hp, ap) : CH_CLOB_X, CH_CLOB_Y);
+        asm volatile("; CHAN lo_y\n\t" CH_LOAD_X2 CH_S4(0, 1, 2, 3, s36, s37, s38, s39) CH_S4(4, 5, 6, 7, s40, s41, s42, s43)
+                     CH_Y4(0, 1, 2, 3, s44, s45, s46, s47) CH_Y4(4, 5, 6, 7, s48, s49, s50, s51) "s_nop 0"
+                     CH_OPERANDS(hp, ap) : CH_CLOB);
     else
-        asm volatile("s_load_dwordx8 s[68:75], %[ptr], 0x0\n\t"
-                     CH_S4(0, 1, 2, 3, s84, s85, s86, s87) CH_S4(4, 5, 6, 7, s88, s89, s90, s91)
-                     "s_waitcnt lgkmcnt(0)"
-                     CH_OPERANDS(hp, ap) : CH_CLOB_X, CH_CLOB_Y);
+        asm volatile("; CHAN lo_y\n\t" CH_LOAD_X1 CH_S4(0, 1, 2, 3, s36, s37, s38, s39) CH_S4(4, 5, 6, 7, s40, s41, s42, s43) "s_nop 0"
+                     CH_OPERANDS(hp, ap) : CH_CLOB);
 }
-// the first half row of a segment into X
+template <int PASS>
+__device__ __forceinline__ void chan_hi_y(float* hp, const float* ap, float dl, float w, float& y0, float& y1) {
+    float t0, t1, t2, t3, u0, u1, u2, u3;
+    const float* next = nullptr;
+    if (PASS == 2)
+        asm volatile("; CHAN hi_y\n\t" CH_S4(0, 1, 2, 3, s52, s53, s54, s55) CH_S4(4, 5, 6, 7, s56, s57, s58, s59)
+                     CH_Y4(0, 1, 2, 3, s60, s61, s62, s63) CH_Y4(4, 5, 6, 7, s64, s65, s66, s67) "s_waitcnt lgkmcnt(0)"
+                     CH_OPERANDS(hp, ap) : CH_CLOB);
+    else
+        asm volatile("; CHAN hi_y\n\t" CH_S4(0, 1, 2, 3, s52, s53, s54, s55) CH_S4(4, 5, 6, 7, s56, s57, s58, s59) "s_waitcnt lgkmcnt(0)"
+                     CH_OPERANDS(hp, ap) : CH_CLOB);
+}
+// the first row of a segment into X
 template <int PASS>
 __device__ __forceinline__ void chan_prime_x(const float* next) {
-    if (PASS == 2) asm volatile("s_load_dwordx16 s[68:83], %[ptr], 0x0\n\ts_waitcnt lgkmcnt(0)" : : [ptr] "s"(next) : CH_CLOB_X, CH_CLOB_Y);
-    else           asm volatile("s_load_dwordx8 s[68:75], %[ptr], 0x0\n\ts_waitcnt lgkmcnt(0)" : : [ptr] "s"(next) : CH_CLOB_X, CH_CLOB_Y);
+    if (PASS == 2) asm volatile(CH_LOAD_X2 "s_waitcnt lgkmcnt(0)" : : [ptr] "s"(next) : CH_CLOB);
+    else           asm volatile(CH_LOAD_X1 "s_waitcnt lgkmcnt(0)" : : [ptr] "s"(next) : CH_CLOB);
 }
 
 typedef const __attribute__((address_space(4))) vivim_ssm_fwd_params* kparams_t;
@@ -210,42 +240,51 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
     asm volatile("s_waitcnt vmcnt(0)" : : "v"(l2_touch));
     chan_prime_x<PASS>(bc + (int64_t)tile_lo * TT * 32);
 
+    // Tile I/O is double-buffered through registers: while tile i is processed out of LDS, the global loads of tile
+    // i + 1 are in flight into `nu / nd / nz`; they are written to LDS after tile i's results have left it.
+    union tile_regs { RawK<T, EPV> r; v4 v; };
+    tile_regs nu[NIO], nd[NIO], nz[NIO];
+    auto issue_tile_loads = [&](int tile) {
+        kparams_t q = fresh_params();
+        // Unconditional loads (countable vmcnt: a load under a branch would make the next wait a full drain); columns past
+        // the end are clamped onto the row's last vector -- their tokens are never processed (blocks stop at L, the
+        // tile after the segment's last is never read)
+        const int t = min(__builtin_amdgcn_readfirstlane(tile * TT) + io_col * EPV, L - EPV);
+        const int64_t su = q->u_d_stride, sd = q->delta_d_stride;
+        const T* gu = static_cast<const T*>(q->u) + b * q->u_batch_stride + (c0 + io_row0) * su + t;
+        const T* gd = static_cast<const T*>(q->delta) + b * q->delta_batch_stride + (c0 + io_row0) * sd + t;
+#pragma unroll
+        for (int i = 0; i < NIO; ++i) {
+            nu[i].v = *reinterpret_cast<const v4*>(gu + i * RPI * su);
+            nd[i].v = *reinterpret_cast<const v4*>(gd + i * RPI * sd);
+        }
+        if (NARR == 3) {
+            const int64_t sz = q->z_d_stride;
+            const T* gz = static_cast<const T*>(q->z) + b * q->z_batch_stride + (c0 + io_row0) * sz + t;
+#pragma unroll
+            for (int i = 0; i < NIO; ++i) nz[i].v = *reinterpret_cast<const v4*>(gz + i * RPI * sz);
+        }
+    };
+    auto tile_regs_to_lds = [&] {
+#pragma unroll
+        for (int i = 0; i < NIO; ++i) {
+            const int off = (i * RPI + io_row0) * ROWB + io_col * 16;
+            *reinterpret_cast<v4*>(tile_u + off) = nu[i].v;
+            *reinterpret_cast<v4*>(tile_d + off) = nd[i].v;
+            if (NARR == 3) *reinterpret_cast<v4*>(tile_z + off) = nz[i].v;
+        }
+    };
+    issue_tile_loads(tile_lo);
+    tile_regs_to_lds();
+    wave_lds_fence();
+
 #pragma unroll 1
     for (int tile = tile_lo; tile < tile_hi; ++tile) {
         const int t0 = __builtin_amdgcn_readfirstlane(tile * TT);
-        // ---- global -> LDS (coalesced 64-byte row segments) ----
-        {
-            kparams_t q = fresh_params();
-            const int t = t0 + io_col * EPV;
-            const bool ok = t < L;                    // L % EPV == 0 (host): a 16-byte column is all-in or all-out
-            const int64_t su = q->u_d_stride, sd = q->delta_d_stride;
-            const T* gu = static_cast<const T*>(q->u) + b * q->u_batch_stride + (c0 + io_row0) * su + t;
-            const T* gd = static_cast<const T*>(q->delta) + b * q->delta_batch_stride + (c0 + io_row0) * sd + t;
-            union { RawK<T, EPV> r; v4 v; } cu[NIO], cd[NIO], cz[NIO];
-            // one vector load touches the 64-byte lines of the NEXT tile's BC rows: they are in this XCD's L2 by
-            // the time the scalar loads want them (first touch would otherwise come from beyond the L2)
-            if (lane < TT * 2) l2_touch = bc[(int64_t)min(t0 + TT + (lane >> 1), sg.Lpad) * 32 + (lane & 1) * 16];
-#pragma unroll
-            for (int i = 0; i < NIO; ++i) {
-                cu[i].r = load_vec<T, EPV>(gu + i * RPI * su, ok);
-                cd[i].r = load_vec<T, EPV>(gd + i * RPI * sd, ok);
-            }
-            if (NARR == 3) {
-                const int64_t sz = q->z_d_stride;
-                const T* gz = static_cast<const T*>(q->z) + b * q->z_batch_stride + (c0 + io_row0) * sz + t;
-#pragma unroll
-                for (int i = 0; i < NIO; ++i) cz[i].r = load_vec<T, EPV>(gz + i * RPI * sz, ok);
-            }
-#pragma unroll
-            for (int i = 0; i < NIO; ++i) {
-                const int off = (i * RPI + io_row0) * ROWB + io_col * 16;
-                *reinterpret_cast<v4*>(tile_u + off) = cu[i].v;
-                *reinterpret_cast<v4*>(tile_d + off) = cd[i].v;
-                if (NARR == 3) *reinterpret_cast<v4*>(tile_z + off) = cz[i].v;
-            }
-        }
-        asm volatile("" : : "v"(l2_touch));          // the touch load must not be optimised away
-        wave_lds_fence();
+        // one vector load touches the 64-byte lines of the NEXT tile's BC rows: they are in this XCD's L2 by the time
+        // the scalar loads want them (first touch would otherwise come from beyond the L2)
+        if (lane < TT * 2) l2_touch = bc[(int64_t)min(t0 + TT + (lane >> 1), sg.Lpad) * 32 + (lane & 1) * 16];
+        issue_tile_loads(tile + 1);                       // predicated off past the segment's last tile
         // ---- the lane's own row: TT tokens in blocks of TB (one 8- or 16-byte LDS access per stream) ----
 #pragma unroll 1
         for (int blk = 0; blk < TT / TB; ++blk) {
@@ -273,11 +312,15 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
             }
             const float* bct = bc + (int64_t)tb * 32;     // uniform: this block's first BC row
 #pragma unroll
-            for (int k = 0; k < TB; ++k) {
+            for (int k = 0; k < TB; k += 2) {             // tokens alternate between the two scalar sets
                 float y1 = 0.0f;
-                chan_half_x<PASS>(h, A2, dl[k], w[k], yo[k], y1, bct + k * 32 + 16);          // prefetch: own high half
-                chan_half_y<PASS>(h + 8, A2 + 8, dl[k], w[k], yo[k], y1, bct + (k + 1) * 32); // prefetch: next token
+                chan_lo_x<PASS>(h, A2, dl[k], w[k], yo[k], y1, bct + (k + 1) * 32);           // prefetch: token k + 1 -> Y
+                chan_hi_x<PASS>(h + 8, A2 + 8, dl[k], w[k], yo[k], y1);
                 if (PASS == 2) yo[k] += y1;
+                y1 = 0.0f;
+                chan_lo_y<PASS>(h, A2, dl[k + 1], w[k + 1], yo[k + 1], y1, bct + (k + 2) * 32);   // token k + 2 -> X
+                chan_hi_y<PASS>(h + 8, A2 + 8, dl[k + 1], w[k + 1], yo[k + 1], y1);
+                if (PASS == 2) yo[k + 1] += y1;
             }
             if (PASS == 2) {
                 // state after every kChunk tokens and after the last one: always the last token of a block
@@ -322,6 +365,9 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
             }
             wave_lds_fence();
         }
+        asm volatile("" : : "v"(l2_touch));              // the touch load must not be optimised away (consumed only now)
+        tile_regs_to_lds();                              // tile + 1: its loads had a whole tile to land
+        wave_lds_fence();
     }
     if (PASS == 1) {
         float* Hs = sg.H + (((int64_t)b * p.dim + d) * sg.S + seg) * N;
@@ -395,14 +441,18 @@ static void fwd_chan_segmentation(const vivim_ssm_fwd_params& f, int tt, int& S,
 static bool fwd_chan_eligible(const vivim_ssm_fwd_params& p, bool shape_only = false) {
     if (!p.is_variable_B || !p.is_variable_C || p.dstate != kChN || p.seqlen % 8 != 0) return false;
     if (p.dim % p.n_groups != 0 || (p.dim / p.n_groups) % kWave != 0) return false;   // whole 64-channel blocks per group
-    // Automatic choice: long rows with enough 64-channel blocks (the grouped v3 stage 0: 336 vs 369 us; cfg 3 grouped
-    // stage 0: 3085 vs 3453 us).  With fewer wave-tokens the kernels are latency-bound and n-split wins (per-direction
-    // stage 0: 154 vs 127 us; L 5120: 176 vs 159 us) -- DESIGN.md 4.7.  Tuning 5 forces it, any other value excludes it.
+    // Automatic choice, from tools/kbench.py on MI355X (us, this family vs n-split; cols = batch * dim / 64 waves' worth of
+    // channels, work = cols * seqlen wave-tokens):
+    //   grouped v3 stages 0-3 (cols 18/36/90/144, work 368k/184k/115k/46k): 309/140/104/64 vs 369/159/112/68
+    //   per-direction stages 0-3 (cols 6/12/30/48, work 123k/61k/38k/15k):  135/84/60/37  vs 131/65/39/29
+    //   cfg 3 stage 0 fp32 (cols 16, work 1.3M): 997 vs 1189;  grouped (cols 48, 3.9M): 2883 vs 3453
+    // -> enough total work AND enough independent channel blocks; otherwise the two passes + carry are latency-bound
+    // and n-split wins.  Tuning 5 forces this family, any other non-zero value excludes it.
     const int tune = tuning_fwd_variant();
     if (tune != 5) {
         if (tune != 0) return false;
-        const int64_t wave_tokens = (int64_t)p.batch * (p.dim / kWave) * p.seqlen;
-        if (p.seqlen < 16384 || wave_tokens < 300000) return false;
+        const int64_t cols = (int64_t)p.batch * (p.dim / kWave);
+        if (cols < 8 || cols * p.seqlen < 110000) return false;
     }
     const int64_t epv = p.itype == VIVIM_F32 ? 4 : 8;
     auto al = [&](const void* q) { return shape_only || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
