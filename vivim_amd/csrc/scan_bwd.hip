@@ -754,13 +754,12 @@ __global__ void ssm_bwd_carry_kernel(const vivim_ssm_bwd_params p, const BwdSeg 
 }
 
 // Tokens per lane of the fast backward.  Most of a state iteration is scan machinery whose cost does not depend on K
-// (DESIGN.md 4.3), so 8 tokens per lane (512-token steps) nearly halve the instructions per state update: measured
-// -4 ... -25 % on Vivim's shapes -- except where the last 512-token step would be mostly empty (L = 1280: three steps,
-// 20 % of the slots idle, +6 % against five full 256-token steps).  fp32 stays at 4 (its per-token registers are twice as
-// wide: 8 would not fit the 256 VGPRs available at two waves per SIMD).  A pure function of (dtype, seqlen): the
-// workspace query and the launch must agree.
-static int bwd_tokens_per_lane(int itype, int seqlen) {
-    if (itype == VIVIM_F32) return 4;
+// (DESIGN.md 4.3), so 8 tokens per lane (512-token steps, 229-243 VGPRs of the 256 available at two waves per SIMD, no
+// scratch) nearly halve the instructions per state update: measured -4 ... -25 % on Vivim's bf16 shapes, -4 ... -9 % on
+// the fp32 ones -- except where the last 512-token step would be mostly empty (L = 1280: three steps, 20 % of the
+// slots idle, +6 % against five full 256-token steps).  A pure function of the shape: the workspace query and the
+// launch must agree.
+static int bwd_tokens_per_lane(int /*itype*/, int seqlen) {
     const int64_t slots8 = (int64_t)((seqlen + 511) / 512) * 512, slots4 = (int64_t)((seqlen + 255) / 256) * 256;
     return slots8 * 100 > slots4 * 115 ? 4 : 8;
 }
@@ -868,7 +867,7 @@ static bool try_bwd_fast_k(const vivim_ssm_bwd_params& p, hipStream_t stream) {
 
 template <typename T>
 static bool try_bwd_fast(const vivim_ssm_bwd_params& p, hipStream_t stream) {
-    if (sizeof(T) == 2 && bwd_tokens_per_lane(p.f.itype, p.f.seqlen) == 8) return try_bwd_fast_k<T, sizeof(T) == 2 ? 8 : 4>(p, stream);
+    if (bwd_tokens_per_lane(p.f.itype, p.f.seqlen) == 8) return try_bwd_fast_k<T, 8>(p, stream);
     return try_bwd_fast_k<T, 4>(p, stream);
 }
 
