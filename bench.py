@@ -3,7 +3,7 @@
 256x256, clip_length 5, 3 classes, per-GPU batch 3, bf16 autocast (BASELINE.json configs[1]); weak scaling
 over N GPUs (one process per GPU, RCCL gradient all-reduce overlapped with the backward by DDP buckets).
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 1 --steps 30 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -35,8 +35,8 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)      # ~2.5 s timed: the step is host-bound and short runs are noisy
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("-image_size", "--image-size", type=int, default=256)
     ap.add_argument("-clip_length", "--clip-length", type=int, default=5)
     ap.add_argument("-train_bs", "--train-bs", type=int, default=3)
