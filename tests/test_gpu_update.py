@@ -108,3 +108,23 @@ def test_update_errors(cuda):
     with pytest.raises(RuntimeError):
         selective_state_update(torch.randn(2, 8, 4, device=cuda), x, x, torch.randn(8, 5, device=cuda),
                                torch.randn(2, 4, device=cuda), torch.randn(2, 4, device=cuda))
+
+
+def test_module_step_matches_full_sequence(cuda):
+    """Mamba.step (the reference's stock single-direction decode step, mamba_simple.py:356-399) chained over a sequence
+    reproduces the full-sequence forward-direction path built from the same parameters (in_proj -> fused inner op ->
+    out_proj, i.e. mamba_inner_fn of mamba_simple.py:300-323)."""
+    from mamba_ssm import Mamba
+    from mamba_ssm.ops.selective_scan_interface import mamba_inner_fn
+    torch.manual_seed(3)
+    m = Mamba(d_model=32, d_state=16, d_conv=4, expand=2, bimamba_type="v3").to(cuda)
+    B, L = 2, 24
+    x = torch.randn(B, L, 32, device=cuda)
+    with torch.no_grad():
+        xz = (m.in_proj.weight @ x.reshape(B * L, -1).t()).view(2 * m.d_inner, B, L).transpose(0, 1)
+        full = mamba_inner_fn(xz, m.conv1d.weight, m.conv1d.bias, m.x_proj.weight, m.dt_proj.weight, m.out_proj.weight,
+                              m.out_proj.bias, -torch.exp(m.A_log.float()), None, None, m.D.float(),
+                              delta_bias=m.dt_proj.bias.float(), delta_softplus=True)
+        conv_state, ssm_state = m.allocate_inference_cache(B, L)
+        outs = [m.step(x[:, t:t + 1], conv_state, ssm_state)[0] for t in range(L)]
+    assert rel_err(torch.cat(outs, dim=1), full) < 2e-5

@@ -7,7 +7,9 @@ Deliberate differences:
   * `nframes` is honoured per call: the reference hard-codes 5 (mamba_simple.py:54) and its
     chunk/stack re-ordering raises for clips whose token count is not 5 equal chunks; here the
     frame-major -> pixel-major permutation is an exact reshape for any nframes dividing seqlen.
-  * decode-time `step` / inference cache (mamba_simple.py:356-443) is outside Vivim's path: not built.
+  * `step` / `allocate_inference_cache` (mamba_simple.py:356-413) are the stock single-direction decode step of the
+    reference (forward-direction parameters only), here on the single-token HIP kernels; the `inference_params` cache
+    plumbing of `forward` (mamba_simple.py:188-200) is not built -- Vivim never passes it.
 """
 import math
 
@@ -18,7 +20,9 @@ import torch.nn.functional as F
 import os
 
 from .dirmap import combine_directions, stack_directions
+from .causal_conv1d_interface import causal_conv1d_update
 from .selective_scan_interface import mamba_inner_fn_no_out_proj, mamba_inner_grouped_fn_no_out_proj
+from .selective_state_update import selective_state_update
 
 _DIRECTIONS = ("", "_b", "_s")     # forward in time, backward in time, spatial (pixel-major) order
 
@@ -125,3 +129,27 @@ class Mamba(nn.Module):
         out_s = out_s.reshape(batch, self.d_inner, hw, nf).transpose(2, 3).reshape(batch, self.d_inner, seqlen)
         y = (out + out_b + out_s).transpose(1, 2) / 3
         return F.linear(y, self.out_proj.weight, self.out_proj.bias)
+
+    def step(self, hidden_states, conv_state, ssm_state):
+        """One token through the forward-direction recurrence (mamba_simple.py:356-399): hidden_states (B, 1, d_model),
+        conv_state (B, d_inner, d_conv) and ssm_state (B, d_inner, d_state) advanced in place
+        -> (out (B, 1, d_model), conv_state, ssm_state)."""
+        assert hidden_states.shape[1] == 1, "Only support decoding with 1 token at a time for now"
+        xz = self.in_proj(hidden_states.squeeze(1))                       # (B, 2D)
+        x, z = xz.chunk(2, dim=-1)
+        x = causal_conv1d_update(x.contiguous(), conv_state, self.conv1d.weight.squeeze(1), self.conv1d.bias, self.activation)
+        x_db = self.x_proj(x)                                             # (B, dt_rank + 2 * d_state)
+        dt, B, C = torch.split(x_db, [self.dt_rank, self.d_state, self.d_state], dim=-1)
+        dt = F.linear(dt, self.dt_proj.weight)                            # the bias goes in with the softplus below
+        A = -torch.exp(self.A_log.float())
+        y = selective_state_update(ssm_state, x, dt, A, B, C, self.D, z=z, dt_bias=self.dt_proj.bias, dt_softplus=True)
+        return self.out_proj(y).unsqueeze(1), conv_state, ssm_state
+
+    def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):
+        """Zero conv / ssm states for `step` (mamba_simple.py:401-413)."""
+        device = self.out_proj.weight.device
+        conv_state = torch.zeros(batch_size, self.d_inner, self.d_conv, device=device,
+                                 dtype=self.conv1d.weight.dtype if dtype is None else dtype)
+        ssm_state = torch.zeros(batch_size, self.d_inner, self.d_state, device=device,
+                                dtype=self.dt_proj.weight.dtype if dtype is None else dtype)
+        return conv_state, ssm_state
