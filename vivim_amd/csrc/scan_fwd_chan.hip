@@ -429,6 +429,8 @@ static void fwd_chan_segmentation(const vivim_ssm_fwd_params& f, int tt, int& S,
     const int ntiles = (f.seqlen + tt - 1) / tt;
     const int cpg = f.dim / f.n_groups;
     const int64_t waves = (int64_t)((cpg + kWave - 1) / kWave) * f.n_groups * f.batch;
+    // 2048 waves: swept 512 ... 8192 on the grouped cfg-2 shapes (309/144/106/64 us at 2048; 377/198/130/68 at 1024;
+    // 320/167/125/70 at 4096)
     int64_t want = (2048 + waves - 1) / waves;
     if (want > ntiles) want = ntiles;
     if (want > 512) want = 512;       // the carry kernel keeps a whole chain in LDS: 512 * 17 * 4 = 34 KB
