@@ -77,3 +77,42 @@ def test_dwconv_full_size(cuda):
     lhs = (y.detach().double() * dy.double()).sum()
     rhs = (x.detach().double() * x.grad.double()).sum()
     assert abs(float(lhs - rhs)) / abs(float(lhs)) < 2e-2      # both sides carry bf16 rounding of y and dx
+
+
+def test_dwconv_random_cases(cuda):
+    """Hypothesis-drawn geometries (depth 1..8, odd heights / widths, channel counts from 2 to 512, 2-D and 3-D taps,
+    with and without bias, all dtypes) against the fp32 torch convolution, forward and all three gradients."""
+    hyp = pytest.importorskip("hypothesis")
+    st = hyp.strategies
+    from vivim_amd.dwconv import depthwise_conv_tokens, supported
+
+    @hyp.settings(max_examples=60, deadline=None, derandomize=True, suppress_health_check=list(hyp.HealthCheck))
+    @hyp.given(B=st.integers(1, 3), D=st.integers(1, 8), H=st.integers(1, 12), W=st.integers(1, 12),
+               C=st.sampled_from([2, 8, 24, 64, 130, 512]), k3=st.booleans(), has_bias=st.booleans(),
+               dtype=st.sampled_from([torch.float32, torch.bfloat16, torch.float16]), seed=st.integers(0, 999))
+    def run(B, D, H, W, C, k3, has_bias, dtype, seed):
+        if not k3:
+            D = 1
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(B, D * H * W, C, generator=g).to(dtype).to(cuda).requires_grad_(True)
+        w = (torch.randn(*((C, 1, 3, 3, 3) if k3 else (C, 1, 3, 3)), generator=g) * 0.3).to(cuda).requires_grad_(True)
+        b = torch.randn(C, generator=g).to(cuda).requires_grad_(True) if has_bias else None
+        if not supported(x, w):
+            return
+        dy = torch.randn(B, D * H * W, C, generator=g).to(dtype).to(cuda)
+        y = depthwise_conv_tokens(x, w, b, D, H, W)
+        y.backward(dy)
+        got = (y.detach(), x.grad.clone(), w.grad.clone(), None if b is None else b.grad.clone())
+        x.grad = w.grad = None
+        if b is not None:
+            b.grad = None
+        yr = _ref(x, w, b, D, H, W)
+        yr.backward(dy.float())
+        tol = 2e-5 if dtype == torch.float32 else 1e-3
+        assert rel_err(got[0].float(), yr.detach().to(dtype).float()) < tol
+        assert rel_err(got[1].float(), x.grad.to(dtype).float()) < tol
+        assert rel_err(got[2], w.grad) < (1e-4 if dtype == torch.float32 else 3e-3)
+        if b is not None:
+            assert rel_err(got[3], b.grad) < (1e-4 if dtype == torch.float32 else 3e-3)
+
+    run()
