@@ -616,7 +616,9 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
 // tokens of a 256-token step; the running sums live in wave-private LDS [state][channel][lane] because the state
 // loop cannot be unrolled for a run-time N; they are reduced over the lanes once per segment.
 constexpr int kPreW = 4;           // independent waves per workgroup (fewer when N * 512 bytes per wave would pass 64 KB)
-template <typename T, int K, bool HAS_Z>
+// NS = 16: the state count is known at compile time (Vivim), the 32 running sums of a lane stay in registers and the
+// state loop is unrolled on packed channel pairs; NS = 0: any N, running sums in LDS.
+template <typename T, int K, bool HAS_Z, int NS>
 __global__ void __launch_bounds__(kPreW * kWave) ssm_bwd_prepass_kernel(const vivim_ssm_bwd_params p, const BwdSeg sg) {
     constexpr int R = kBwR;
     constexpr int TILE = kWave * K;
@@ -641,7 +643,11 @@ __global__ void __launch_bounds__(kPreW * kWave) ssm_bwd_prepass_kernel(const vi
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* acc = smem + wave * (N * R * kWave);        // [n][r][lane]
-    for (int i = lane; i < N * R * kWave; i += kWave) acc[i] = 0.0f;
+    if (NS == 0)
+        for (int i = lane; i < N * R * kWave; i += kWave) acc[i] = 0.0f;
+    f2 racc[NS > 0 ? NS : 1];
+#pragma unroll
+    for (int n = 0; n < (NS > 0 ? NS : 1); ++n) racc[n] = f2{0.0f, 0.0f};
 
     int d[R];
     float bias[R], a2v[R];                             // a2v: lane n holds A[d][n] * log2e
@@ -692,20 +698,42 @@ __global__ void __launch_bounds__(kPreW * kWave) ssm_bwd_prepass_kernel(const vi
             base[r] += read_lane(incl, 63);
         }
         RawK<T, K> Craw = load_vec_always<T, K>(Cv + t0, in, Cv);
-#pragma unroll 1
-        for (int n = 0; n < N; ++n) {
-            float Cn[K];
-            unpack(Craw, Cn);
-            Craw = load_vec_always<T, K>(Cv + (n + 1) * f.C_dstate_stride + t0, in && (n + 1 < N), Cv);
+        if (NS > 0) {
+            f2 cp[K], dyp[K];
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const float A2 = read_lane(a2v[r], n);
-                float* q = acc + (n * R + r) * kWave + lane;
-                float v = *q;
+            for (int k = 0; k < K; ++k) { cp[k] = f2{c[0][k], c[1][k]}; dyp[k] = f2{dy[0][k], dy[1][k]}; }
 #pragma unroll
-                for (int k = 0; k < K; ++k) v = fmaf(fast_exp2(A2 * c[r][k]), Cn[k] * dy[r][k], v);
-                *q = v;
+            for (int n = 0; n < NS; ++n) {
+                float Cn[K];
+                unpack(Craw, Cn);
+                Craw = load_vec_always<T, K>(Cv + (n + 1) * f.C_dstate_stride + t0, in && (n + 1 < NS), Cv);
+                const f2 A2 = {read_lane(a2v[0], n), read_lane(a2v[1], n)};
+#pragma unroll
+                for (int k = 0; k < K; ++k) racc[n] = fma2(exp2_2(A2 * cp[k]), dyp[k] * Cn[k], racc[n]);
             }
+        } else {
+#pragma unroll 1
+            for (int n = 0; n < N; ++n) {
+                float Cn[K];
+                unpack(Craw, Cn);
+                Craw = load_vec_always<T, K>(Cv + (n + 1) * f.C_dstate_stride + t0, in && (n + 1 < N), Cv);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float A2 = read_lane(a2v[r], n);
+                    float* q = acc + (n * R + r) * kWave + lane;
+                    float v = *q;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) v = fmaf(fast_exp2(A2 * c[r][k]), Cn[k] * dy[r][k], v);
+                    *q = v;
+                }
+            }
+        }
+    }
+    if (NS > 0) {                                       // hand the register sums to the common reduction below
+#pragma unroll
+        for (int n = 0; n < NS; ++n) {
+            acc[(n * R + 0) * kWave + lane] = racc[n].x;
+            acc[(n * R + 1) * kWave + lane] = racc[n].y;
         }
     }
     wave_lds_fence();
@@ -837,8 +865,13 @@ static void launch_bwd_fast(const vivim_ssm_bwd_params& p, hipStream_t stream) {
         int nw = (int)((size_t)65536 / per_wave);
         nw = nw > kPreW ? kPreW : (nw < 1 ? 1 : nw);
         dim3 gpre(((ppg + nw - 1) / nw) * f.n_groups, f.batch, sg.S - 1);
-        if (f.z) hipLaunchKernelGGL((ssm_bwd_prepass_kernel<T, K, true>), gpre, dim3(nw * kWave), nw * per_wave, stream, p, sg);
-        else     hipLaunchKernelGGL((ssm_bwd_prepass_kernel<T, K, false>), gpre, dim3(nw * kWave), nw * per_wave, stream, p, sg);
+        if (f.dstate == 16) {
+            if (f.z) hipLaunchKernelGGL((ssm_bwd_prepass_kernel<T, K, true, 16>), gpre, dim3(nw * kWave), nw * per_wave, stream, p, sg);
+            else     hipLaunchKernelGGL((ssm_bwd_prepass_kernel<T, K, false, 16>), gpre, dim3(nw * kWave), nw * per_wave, stream, p, sg);
+        } else {
+            if (f.z) hipLaunchKernelGGL((ssm_bwd_prepass_kernel<T, K, true, 0>), gpre, dim3(nw * kWave), nw * per_wave, stream, p, sg);
+            else     hipLaunchKernelGGL((ssm_bwd_prepass_kernel<T, K, false, 0>), gpre, dim3(nw * kWave), nw * per_wave, stream, p, sg);
+        }
         const int64_t nthr = (int64_t)f.batch * f.dim * f.dstate;
         hipLaunchKernelGGL(ssm_bwd_carry_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream, p, sg);
     }
