@@ -83,6 +83,22 @@ def cpu_baseline(seconds_budget=12.0):
                       f"{os.cpu_count()} host cpus"}
 
 
+def measured_copy_ceiling(dev, nbytes=1 << 30, iters=10):
+    """Device-to-device copy rate on this GPU (read + write bytes / time): the practical HBM ceiling SURVEY.md 8d asks to
+    report beside the nominal 8 TB/s.  Runs after the timed region."""
+    src = torch.empty(nbytes, dtype=torch.uint8, device=dev).fill_(1)
+    dst = torch.empty_like(src)
+    for _ in range(2):
+        dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return round(2 * nbytes * iters / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+
+
 def pmc_traffic(entry_point):
     """HBM bytes per launch of a hot-path entry point as measured by rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over
     this very command (tools/pmc_bench_traffic.py; bench.py cannot run the profiler on itself): the newest committed
@@ -174,8 +190,8 @@ def main():
                          "traffic": traffic, "traffic_unit": "bytes per launch (PMC, separate passes)",
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(per[dom][0] / per[dom][2]),
                          "launches": per[dom][2],
-
-                         "avg_launch_us": round(per[dom][1] / per[dom][2] * 1e6, 2)},
+                         "avg_launch_us": round(per[dom][1] / per[dom][2] * 1e6, 2),
+                         "measured_copy_GBps": measured_copy_ceiling(dev)},
             "kernels": kernels,
             "loss": round(float(loss), 5),
         }

@@ -116,7 +116,9 @@ typedef struct {
     int32_t wtype;                       /* dtype of weight and bias */
     int32_t silu_activation;
     int32_t _pad0;
-    int64_t x_batch_stride, x_c_stride, x_l_stride;         /* x_l_stride must be 1 (channel-first) */
+    int64_t x_batch_stride, x_c_stride, x_l_stride;         /* x_l_stride == 1 (channel-first), or x_c_stride == 1 and
+                                                               x_l_stride > 1 (channel-last, causal_conv1d.cpp:151):
+                                                               out / dout / dx must then have unit channel stride too */
     int64_t out_batch_stride, out_c_stride, out_l_stride;
     int64_t weight_c_stride, weight_width_stride;
     const void *x;              /* (batch, dim, seqlen) */

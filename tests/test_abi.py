@@ -48,8 +48,11 @@ def test_rejects_before_launch():
     assert b"width between 2 and 4" in L.vivim_last_error()
     p.width, p.itype = 4, 7
     assert L.vivim_causal_conv1d_fwd(ctypes.byref(p), None) == 1
-    p.itype, p.x_l_stride = 0, 4
-    assert L.vivim_causal_conv1d_fwd(ctypes.byref(p), None) == 2          # channel-last: unsupported
+    p.itype, p.x_l_stride, p.x_c_stride = 0, 4, 2
+    assert L.vivim_causal_conv1d_fwd(ctypes.byref(p), None) == 1          # neither seqlen nor channels contiguous
+    assert b"unit stride along seqlen or along channels" in L.vivim_last_error()
+    p.x_c_stride = 1                                                      # channel-last x needs a channel-last out
+    assert L.vivim_causal_conv1d_fwd(ctypes.byref(p), None) == 1
     s = _lib.SsmFwdParams()
     s.batch = s.dim = s.seqlen = s.n_groups = 1
     s.dstate = 300

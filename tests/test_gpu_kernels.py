@@ -176,6 +176,43 @@ def test_conv_channel_last(dtype, cuda, ops):
     assert rel_err(res[1][0].float(), _round(r, dtype)) < _tol(dtype)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(1, 4, 1, 4), (2, 30, 151, 3), (3, 64, 2049, 4), (1, 257, 700, 2), (2, 384, 5120, 4)])
+@pytest.mark.parametrize("silu,has_bias", [(True, True), (False, False)])
+def test_conv_channel_last_oracle(dtype, shape, silu, has_bias, cuda, ops):
+    """Native channel-last kernels (csrc/conv1d_cl.hip) against the oracle: ragged channel counts (not a multiple of the
+    4 channels a lane owns), every width, several token chunks, and a token stride wider than the row (a channel slice of
+    a wider channel-last tensor, which also breaks the 8/16-byte alignment of the rows)."""
+    _, cc = ops
+    B, D, L, W = shape
+    g = torch.Generator().manual_seed(B * 1000 + D + L + W)
+    wide = torch.randn(B, L, D + 3, generator=g).to(dtype).to(cuda)
+    for x in (wide[:, :, :D].contiguous().transpose(1, 2), wide[:, :, 1:D + 1].transpose(1, 2)):
+        assert x.shape == (B, D, L) and x.stride(1) == 1
+        w = torch.randn(D, W, generator=g).to(cuda)
+        b = torch.randn(D, generator=g).to(cuda) if has_bias else None
+        dout = torch.randn(B, L, D, generator=g).to(dtype).to(cuda).transpose(1, 2)
+        y = cc.causal_conv1d_fwd(x, w, b, silu)
+        assert y.stride(1) == 1 and y.shape == x.shape
+        r = cpu_oracle.causal_conv1d_fwd(x, w, b, silu)
+        tol = _tol(dtype)
+        assert rel_err(y.float(), _round(r, dtype)) < tol
+        dx, dw, db = cc.causal_conv1d_bwd(x, w, b, dout, None, silu)
+        assert dx.stride(1) == 1
+        rdx, rdw, rdb = cpu_oracle.causal_conv1d_bwd(x, w, b, dout, silu)
+        gt = max(tol, 1e-4) * (4 if dtype != torch.float32 else 1)
+        assert rel_err(dx.float(), _round(rdx, dtype)) < gt
+        assert rel_err(dw.float(), rdw) < gt * 2
+        if has_bias:
+            assert rel_err(db.float(), rdb) < gt * 2
+        else:
+            assert db is None
+        # channel-first dout is accepted and re-laid (causal_conv1d.cpp:221); a caller-owned dx is written in place
+        dx2 = torch.empty(B, L, D, dtype=dtype, device=cuda).transpose(1, 2)
+        out = cc.causal_conv1d_bwd(x, w, b, dout.contiguous(), dx2, silu)
+        assert out[0] is dx2 and torch.equal(dx2, dx)
+
+
 def test_conv_errors(cuda, ops):
     _, cc = ops
     from causal_conv1d import causal_conv1d_fn

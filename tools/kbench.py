@@ -2,7 +2,9 @@
 """Kernel micro-benchmark: times the four hot-path kernels (through the C ABI) on the stage shapes of a
 BASELINE.json config and prints achieved algorithmic GB/s (SURVEY.md section 8d formulas).
 Usage: python tools/kbench.py [--config 2|3|5] [--iters 20] [--stages 0,1,2,3] [--kernels sf,sb,cf,cb] [--groups 3]
---groups 3: the grouped v3 shapes (three directions side by side: dim = 3 * d_inner, n_groups = 3, contiguous rows)."""
+--groups 3: the grouped v3 shapes (three directions side by side: dim = 3 * d_inner, n_groups = 3, contiguous rows).
+--cold S: cycle S independent input sets (S >= 3 and S * set size > the 256 MB Infinity Cache: no launch finds its inputs
+in a cache).  --ceiling: also print the device-to-device copy rate (the practical HBM ceiling)."""
 import argparse
 import os
 import sys
@@ -51,30 +53,57 @@ def main():
     ap.add_argument("--stages", default="0,1,2,3")
     ap.add_argument("--kernels", default="sf,sb,cf,cb")
     ap.add_argument("--groups", type=int, default=1)
+    ap.add_argument("--cold", type=int, default=1)
+    ap.add_argument("--ceiling", action="store_true")
     a = ap.parse_args()
     B, nf, img, N, expand, dt = CONFIGS[a.config]
     s = torch.finfo(dt).bits // 8
     dev = torch.device("cuda:0")
-    print(f"config {a.config}: B={B} nf={nf} img={img} N={N} expand={expand} dtype={dt}")
+    print(f"config {a.config}: B={B} nf={nf} img={img} N={N} expand={expand} dtype={dt}" + (f" cold x{a.cold}" if a.cold > 1 else ""))
+    if a.ceiling:
+        src = torch.ones(1 << 30, dtype=torch.uint8, device=dev)
+        dst = torch.empty_like(src)
+        t = timeit(lambda: dst.copy_(src), 10)
+        print(f"  device-to-device copy of 1 GiB: {2 * src.numel() / t / 1e9:8.1f} GB/s (read + write)")
+        del src, dst
     for st in map(int, a.stages.split(",")):
         G = a.groups
         D = DIMS[st] * expand * G
         L = nf * (img // STRIDES[st]) ** 2
         mk = lambda *sh: torch.randn(*sh, device=dev).to(dt)
         strided = (lambda: mk(D, B, L).transpose(0, 1)) if G == 1 else (lambda: mk(B, D, L))
-        u, delta, z, dout = strided(), ((0.2 * torch.randn(D, B, L, device=dev)).to(dt).transpose(0, 1) if G == 1 else (0.2 * torch.randn(B, D, L, device=dev)).to(dt)), strided(), strided()
         A = -torch.arange(1, N + 1, device=dev, dtype=torch.float32).repeat(D, 1)
-        Bm, Cm = mk(B, G, N, L), mk(B, G, N, L)
         Dv, bias = torch.ones(D, device=dev), torch.full((D,), -4.0, device=dev)
         w, cb = torch.randn(D, 4, device=dev), torch.randn(D, device=dev)
-        out, x, out_z = ss.fwd(u, delta, A, Bm, Cm, Dv, z, bias, True)
-        dz = torch.empty_like(z)
-        runs = {
-            "sf": lambda: ss.fwd(u, delta, A, Bm, Cm, Dv, z, bias, True),
-            "sb": lambda: ss.bwd(u, delta, A, Bm, Cm, Dv, z, bias, dout, x, out, dz, True, False),
-            "cf": lambda: cc.causal_conv1d_fwd(u, w, cb, True),
-            "cb": lambda: cc.causal_conv1d_bwd(u, w, cb, dout, None, True),
-        }
+        sets = []
+        for _ in range(max(1, a.cold)):
+            u, z, dout = strided(), strided(), strided()
+            delta = (0.2 * torch.randn(D, B, L, device=dev)).to(dt).transpose(0, 1) if G == 1 else (0.2 * torch.randn(B, D, L, device=dev)).to(dt)
+            Bm, Cm = mk(B, G, N, L), mk(B, G, N, L)
+            out, x, out_z = ss.fwd(u, delta, A, Bm, Cm, Dv, z, bias, True)
+            sets.append((u, delta, z, dout, Bm, Cm, out, x, torch.empty_like(z)))
+        turn = [0]
+
+        def nxt():
+            turn[0] = (turn[0] + 1) % len(sets)
+            return sets[turn[0]]
+
+        def sf():
+            u, delta, z, dout, Bm, Cm, out, x, dz = nxt()
+            return ss.fwd(u, delta, A, Bm, Cm, Dv, z, bias, True)
+
+        def sb():
+            u, delta, z, dout, Bm, Cm, out, x, dz = nxt()
+            return ss.bwd(u, delta, A, Bm, Cm, Dv, z, bias, dout, x, out, dz, True, False)
+
+        def cf():
+            return cc.causal_conv1d_fwd(nxt()[0], w, cb, True)
+
+        def cbw():
+            s_ = nxt()
+            return cc.causal_conv1d_bwd(s_[0], w, cb, s_[3], None, True)
+
+        runs = {"sf": sf, "sb": sb, "cf": cf, "cb": cbw}
         for k in a.kernels.split(","):
             t = timeit(runs[k], a.iters)
             nb = alg_bytes(k, B, D, L, N, s, G)

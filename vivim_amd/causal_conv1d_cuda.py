@@ -1,7 +1,8 @@
 """Drop-in for the reference's `causal_conv1d_cuda` extension module (pybind surface at
 causal-conv1d/csrc/causal_conv1d.cpp:329-333): `causal_conv1d_fwd` / `causal_conv1d_bwd` with the same
 positional signatures, checks and returns, on the gfx950 kernels behind include/vivim_hip.h.
-`causal_conv1d_update` (single-token step for streaming inference; not on Vivim's training path) is built too.
+`causal_conv1d_update` (single-token step for streaming inference) and the channel-last layout (unit stride along
+channels) are built too; neither is on Vivim's training path.
 """
 import torch
 
@@ -51,14 +52,12 @@ def causal_conv1d_fwd(x, weight, bias_, silu_activation):
     """-> out (empty_like(x)); causal_conv1d.cpp:130-189."""
     dims = _checks(x, weight, bias_)
     if _channel_last(x):
-        # The reference has separate channel-last kernels (causal_conv1d_fwd.cu:193-298).  Vivim never produces this
-        # layout, so it is served by the channel-first kernel on a transposed copy; the result comes back in x's layout.
-        out = torch.empty_like(x)
-        out.copy_(causal_conv1d_fwd(x.contiguous(), weight, bias_, silu_activation))
-        return out
-    out = _lib.empty_like(x)
-    if out.stride(2) != 1:       # empty_like of an exotic view may not keep unit seqlen stride
-        out = _lib.empty(tuple(x.shape), x.dtype, x.device)
+        # lanes-along-channels kernels (csrc/conv1d_cl.hip; reference: causal_conv1d_fwd.cu:193-298); out keeps x's layout
+        out = _lib.empty((x.shape[0], x.shape[2], x.shape[1]), x.dtype, x.device).transpose(1, 2)
+    else:
+        out = _lib.empty_like(x)
+        if out.stride(2) != 1:       # empty_like of an exotic view may not keep unit seqlen stride
+            out = _lib.empty(tuple(x.shape), x.dtype, x.device)
     P = _lib.ConvFwdParams()
     _fill(P, x, weight, bias_, silu_activation, dims)
     P.out = out.data_ptr()
@@ -74,21 +73,26 @@ def causal_conv1d_bwd(x, weight, bias_, dout, dx_, silu_activation):
     batch, dim, seqlen, width = dims
     _check(dout.is_cuda and dout.dtype == x.dtype and tuple(dout.shape) == (batch, dim, seqlen),
            "dout must match x")
-    if _channel_last(x):                              # see causal_conv1d_fwd; dx comes back in x's layout
-        dxc, dweight, dbias = causal_conv1d_bwd(x.contiguous(), weight, bias_, dout.contiguous(), None, silu_activation)
-        dx = dx_ if dx_ is not None else torch.empty_like(x)
-        dx.copy_(dxc)
-        return [dx, dweight, dbias]
-    if dout.stride(2) != 1:
-        dout = dout.contiguous()                      # causal_conv1d.cpp:220
-    if dx_ is not None:
-        _check(dx_.dtype == x.dtype and dx_.is_cuda and tuple(dx_.shape) == (batch, dim, seqlen)
-               and dx_.stride(2) == 1, "dx must match x and have stride(2) == 1")
-        dx = dx_
+    if _channel_last(x):                              # csrc/conv1d_cl.hip (reference: causal_conv1d_bwd.cu:306-472)
+        if dout.stride(1) != 1:
+            dout = dout.transpose(-1, -2).contiguous().transpose(-1, -2)      # causal_conv1d.cpp:221
+        if dx_ is not None:
+            _check(dx_.dtype == x.dtype and dx_.is_cuda and tuple(dx_.shape) == (batch, dim, seqlen)
+                   and dx_.stride(1) == 1, "dx must match x and have stride(1) == 1")       # causal_conv1d.cpp:237
+            dx = dx_
+        else:
+            dx = _lib.empty((batch, seqlen, dim), x.dtype, x.device).transpose(1, 2)
     else:
-        dx = _lib.empty_like(x)
-        if dx.stride(2) != 1:
-            dx = _lib.empty(tuple(x.shape), x.dtype, x.device)
+        if dout.stride(2) != 1:
+            dout = dout.contiguous()                  # causal_conv1d.cpp:220
+        if dx_ is not None:
+            _check(dx_.dtype == x.dtype and dx_.is_cuda and tuple(dx_.shape) == (batch, dim, seqlen)
+                   and dx_.stride(2) == 1, "dx must match x and have stride(2) == 1")
+            dx = dx_
+        else:
+            dx = _lib.empty_like(x)
+            if dx.stride(2) != 1:
+                dx = _lib.empty(tuple(x.shape), x.dtype, x.device)
     dweight = torch.zeros(weight.shape, device=x.device, dtype=torch.float32)
     dbias = torch.zeros(dim, device=x.device, dtype=torch.float32) if bias_ is not None else None
     P = _lib.ConvBwdParams()

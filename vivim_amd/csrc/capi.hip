@@ -9,6 +9,8 @@
 namespace vivim {
 bool conv_fwd_dispatch(const vivim_conv_fwd_params&, hipStream_t);
 bool conv_bwd_dispatch(const vivim_conv_bwd_params&, hipStream_t);
+bool conv_cl_fwd_dispatch(const vivim_conv_fwd_params&, hipStream_t);                // conv1d_cl.hip (channel-last)
+bool conv_cl_bwd_dispatch(const vivim_conv_bwd_params&, hipStream_t);
 bool ssm_fwd_dispatch(const vivim_ssm_fwd_params&, hipStream_t);
 bool dwconv_fwd_dispatch(const vivim_dwconv_params&, hipStream_t);
 bool dwconv_wgrad_dispatch(const vivim_dwconv_wgrad_params&, hipStream_t);
@@ -139,16 +141,21 @@ static int check_conv(const vivim_conv_fwd_params* p) {
     if (!(p->width >= 2 && p->width <= 4))          // causal_conv1d.cpp:157
         return fail(VIVIM_ERR_INVALID, "causal_conv1d only supports width between 2 and 4");
     VCHECK(p->x && p->weight);
-    if (p->x_l_stride != 1)
-        return fail(VIVIM_ERR_UNSUPPORTED,
-                    "causal_conv1d: channel-last layout is not built (Vivim's x has unit seqlen stride)");
+    if (p->x_l_stride != 1 && p->x_c_stride != 1)   // causal_conv1d.cpp:151-152
+        return fail(VIVIM_ERR_INVALID, "causal_conv1d: x must have unit stride along seqlen or along channels");
     return VIVIM_OK;
 }
 
+// causal_conv1d.cpp:151: is_channel_last = x.stride(1) == 1 && x.stride(2) > 1
+static bool conv_channel_last(const vivim_conv_fwd_params* p) { return p->x_c_stride == 1 && p->x_l_stride > 1; }
+
 int vivim_causal_conv1d_fwd(const vivim_conv_fwd_params* p, void* stream) {
     if (int rc = check_conv(p)) return rc;
-    VCHECK(p->out != nullptr && p->out_l_stride == 1);
-    if (!vivim::conv_fwd_dispatch(*p, static_cast<hipStream_t>(stream)))
+    VCHECK(p->out != nullptr);
+    const bool cl = conv_channel_last(p);
+    if (cl) { VCHECK(p->out_c_stride == 1); } else { VCHECK(p->out_l_stride == 1); }
+    if (!(cl ? vivim::conv_cl_fwd_dispatch(*p, static_cast<hipStream_t>(stream))
+             : vivim::conv_fwd_dispatch(*p, static_cast<hipStream_t>(stream))))
         return fail(VIVIM_ERR_UNSUPPORTED, "causal_conv1d_fwd not implemented for input type %d / weight type %d",
                     p->itype, p->wtype);
     return after_launch("causal_conv1d_fwd");
@@ -158,9 +165,12 @@ int vivim_causal_conv1d_bwd(const vivim_conv_bwd_params* p, void* stream) {
     VCHECK(p != nullptr);
     if (int rc = check_conv(&p->f)) return rc;
     VCHECK(p->dout && p->dx && p->dweight);
-    VCHECK(p->dout_l_stride == 1 && p->dx_l_stride == 1);   // causal_conv1d.cpp:220, 236
+    const bool cl = conv_channel_last(&p->f);
+    if (cl) { VCHECK(p->dout_c_stride == 1 && p->dx_c_stride == 1); }      // causal_conv1d.cpp:221, 237
+    else    { VCHECK(p->dout_l_stride == 1 && p->dx_l_stride == 1); }      // causal_conv1d.cpp:220, 236
     VCHECK((p->f.bias == nullptr) == (p->dbias == nullptr));
-    if (!vivim::conv_bwd_dispatch(*p, static_cast<hipStream_t>(stream)))
+    if (!(cl ? vivim::conv_cl_bwd_dispatch(*p, static_cast<hipStream_t>(stream))
+             : vivim::conv_bwd_dispatch(*p, static_cast<hipStream_t>(stream))))
         return fail(VIVIM_ERR_UNSUPPORTED, "causal_conv1d_bwd not implemented for input type %d / weight type %d",
                     p->f.itype, p->f.wtype);
     return after_launch("causal_conv1d_bwd");
