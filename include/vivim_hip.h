@@ -247,8 +247,8 @@ size_t vivim_scan_bwd_workspace_bytes(const vivim_ssm_fwd_params *f);
 size_t vivim_scan_fwd_workspace_bytes(const vivim_ssm_fwd_params *f);
 
 /* Kernel-selection override for tuning and tests: which = 0 forward scan (0 automatic, 1 n-split K=8, 2 n-split K=4,
- * 3 generic, 5 lanes=channels), which = 1 backward scan (0 automatic, 3 generic).  Returns the previous value, -1 on a
- * bad argument.  Initial values come from VIVIM_FWD_VARIANT / VIVIM_BWD_VARIANT.  The forward workspace size depends on
+ * 3 generic, 5 lanes=channels), which = 1 backward scan (0 automatic, 1 / 2 fast kernel with 8 / 4 waves per workgroup,
+ * 3 generic).  Returns the previous value, -1 on a bad argument.  Initial values come from VIVIM_FWD_VARIANT / VIVIM_BWD_VARIANT.  The forward workspace size depends on
  * the forward setting: query it after changing it. */
 int vivim_set_tuning(int which, int value);
 

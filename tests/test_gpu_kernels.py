@@ -360,7 +360,7 @@ def test_scan_optional_arguments(has_z, has_D, has_bias, softplus, cuda, ops):
 # Every forward / backward kernel family must agree with the oracle, not only the one the dispatcher prefers:
 # vivim_set_tuning (include/vivim_hip.h) pins the family for the duration of a test.
 FWD_VARIANTS = {"auto": 0, "nsplit_k8": 1, "nsplit_k4": 2, "generic": 3, "channels": 5}
-BWD_VARIANTS = {"auto": 0, "generic": 3}
+BWD_VARIANTS = {"auto": 0, "fast_w8": 1, "fast_w4": 2, "generic": 3}
 
 
 @pytest.fixture
@@ -384,7 +384,8 @@ def tuning():
                                                 (torch.float16, 2, 256, 320, 2), (torch.bfloat16, 1, 192, 8, 1)])
 def test_scan_kernel_families(fwd, bwd, dtype, batch, dim, L, G, cuda, ops, tuning):
     """Vivim-shaped problems (dstate 16, whole 64-channel blocks, aligned rows) are eligible for every family:
-    n-split K=8 / K=4, lanes=channels (token-axis segments + carry kernel), generic; fast / generic backward."""
+    n-split K=8 / K=4, lanes=channels (token-axis segments + carry kernel), generic; fast (8 or 4 waves per workgroup) /
+    generic backward."""
     ss, _ = ops
     tuning(FWD_VARIANTS[fwd], BWD_VARIANTS[bwd])
     gen = torch.Generator().manual_seed(dim + L)

@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(kBwdWaves * kWave) ssm_bwd_generic_kernel(cons
 //     rate.  Slots are double-buffered on the state parity, so one barrier per state suffices;
 //   * every per-(channel, state) scalar the step needs (checkpoint, g carry, first decay of the step to the
 //     right, A, A*log2e, running dA) sits in a per-wave LDS record read with one ds_read_b128 pair.
-constexpr int kBwW = 8;            // waves per workgroup
+constexpr int kBwWmax = 8;         // waves per workgroup: 8 or 4 (template parameter W of the fast kernel)
 constexpr int kBwR = 2;            // channels per wave
 constexpr int kRec = 8;            // floats per (state, channel) record
 
@@ -285,14 +285,14 @@ template <int CTRL> __device__ __forceinline__ f2 dpp_mov2(f2 old, f2 src) {
 // The backward of one segment of the token axis (the whole sequence when S == 1).
 // DA_LDS (N <= 16): dA partial sums stay per lane in LDS and are reduced over the lanes once per segment, instead of
 // one wave reduction per (state, channel) and step.
-template <typename T, int K, bool HAS_Z, int MINW, bool DA_LDS>
-__global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const vivim_ssm_bwd_params p, const BwdSeg sg) {
+template <typename T, int K, bool HAS_Z, int W, bool DA_LDS>
+__global__ void __launch_bounds__(W * kWave, 2) ssm_bwd_fast_kernel(const vivim_ssm_bwd_params p, const BwdSeg sg) {
     constexpr int R = kBwR;
     static_assert(R == 2, "the state loop is written on channel pairs");
     constexpr int TILE = kWave * K;
     static_assert(TILE % kChunk == 0, "a step starts on a checkpoint row");
-    constexpr int EPT = 2 * TILE / (kBwW * kWave);     // (token, dB|dC) elements of a step each thread reduces
-    static_assert(EPT * kBwW * kWave == 2 * TILE, "whole elements per thread");
+    constexpr int EPT = 2 * TILE / (W * kWave);     // (token, dB|dC) elements of a step each thread reduces
+    static_assert(EPT * W * kWave == 2 * TILE, "whole elements per thread");
     const vivim_ssm_fwd_params& f = p.f;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -301,9 +301,9 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
     const int N = f.dstate, L = f.seqlen;
     const int cpg = f.dim / f.n_groups;
     const int ppg = (cpg + R - 1) / R;                 // channel pairs per B/C group
-    const int bpg = (ppg + kBwW - 1) / kBwW;           // workgroups per group
+    const int bpg = (ppg + W - 1) / W;           // workgroups per group
     const int g = blockIdx.x / bpg;
-    const int pair = (blockIdx.x - g * bpg) * kBwW + wave;
+    const int pair = (blockIdx.x - g * bpg) * W + wave;
     const bool active = pair < ppg;                    // surplus waves only help with barriers and the flush
     const int d0 = g * cpg + min(pair, ppg - 1) * R;
     const int nvalid = min(R, (g + 1) * cpg - d0);
@@ -319,8 +319,8 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
     constexpr int NBUF = 2;
     float* slots = smem;                               // [n % NBUF][wave][2K][64]
     // wave-private records, [state][field][channel]: the pair of a field is one 8-byte read
-    float* rec = smem + NBUF * kBwW * SLOT + wave * (N * R * kRec);
-    f2* dAl = reinterpret_cast<f2*>(smem + NBUF * kBwW * SLOT + kBwW * (N * R * kRec)) + wave * (N * kWave);   // [state][lane]
+    float* rec = smem + NBUF * W * SLOT + wave * (N * R * kRec);
+    f2* dAl = reinterpret_cast<f2*>(smem + NBUF * W * SLOT + W * (N * R * kRec)) + wave * (N * kWave);   // [state][lane]
     if (DA_LDS)
         for (int i = lane; i < N * kWave; i += kWave) dAl[i] = f2{0.0f, 0.0f};
     enum { HCK = 0, GCAR = 1, AFIRST = 2, A2VAL = 3, DAACC = 4 };
@@ -520,7 +520,7 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
                     }
                 }
                 {
-                    float* sl = slots + ((n & (NBUF - 1)) * kBwW + wave) * SLOT + lane;
+                    float* sl = slots + ((n & (NBUF - 1)) * W + wave) * SLOT + lane;
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
                         sl[k * kWave] = dBv[k];
@@ -533,13 +533,13 @@ __global__ void __launch_bounds__(kBwW * kWave, MINW) ssm_bwd_fast_kernel(const 
 #pragma unroll
                 for (int j = 0; j < EPT; ++j) {
                     // fixed-order sum over the workgroup's 8 channel pairs, then one fp32 atomic per element
-                    const int e = tid + j * (kBwW * kWave);
+                    const int e = tid + j * (W * kWave);
                     const int e_tok = e & (TILE - 1), e_isC = e / TILE;
-                    const float* sp = slots + (n & (NBUF - 1)) * kBwW * SLOT +
+                    const float* sp = slots + (n & (NBUF - 1)) * W * SLOT +
                                       (e_isC * K + (e_tok & (K - 1))) * kWave + (e_tok / K);
                     float acc = sp[0];
 #pragma unroll
-                    for (int wv = 1; wv < kBwW; ++wv) acc += sp[wv * SLOT];
+                    for (int wv = 1; wv < W; ++wv) acc += sp[wv * SLOT];
                     // fp32 sum over workgroups (bwd_kernel.cuh:312-313).  Unconditional: elements past the end
                     // carry acc == 0 (their dy and delta*u are 0) and are wrapped onto distinct valid tokens.
                     const int tq = step * TILE + e_tok;
@@ -808,58 +808,80 @@ static int device_cu_count() {
     return n;
 }
 
-static void bwd_segmentation(const vivim_ssm_fwd_params& f, int& S, int& seg_steps) {
+// Token-axis cut for workgroups of W waves: minimise rounds-of-the-chip x (steps per segment + fixed cost).
+static void bwd_segmentation(const vivim_ssm_fwd_params& f, int W, int& S, int& seg_steps, int64_t& workgroups) {
     const int tile = kWave * bwd_tokens_per_lane(f.itype, f.seqlen);
     const int nsteps = (f.seqlen + tile - 1) / tile;
     const int cpg = f.dim / f.n_groups;
     const int ppg = (cpg + kBwR - 1) / kBwR;
-    const int64_t base = (int64_t)((ppg + kBwW - 1) / kBwW) * f.n_groups * f.batch;
-    const int ncu = device_cu_count();
+    const int64_t base = (int64_t)((ppg + W - 1) / W) * f.n_groups * f.batch;
+    const int slots = device_cu_count() * (kBwWmax / W);            // workgroups in flight: 8 waves per CU (240 VGPRs each)
     int best = 1;
     double best_cost = 1e300;
     for (int s = 1; s <= nsteps && s <= 64; ++s) {
         const int steps = (nsteps + s - 1) / s;
         if ((nsteps + steps - 1) / steps != s) continue;            // not a distinct cut
-        const double rounds = (double)((base * s + ncu - 1) / ncu);
+        const double rounds = (double)((base * s + slots - 1) / slots);
         const double cost = rounds * (steps + 0.3);
         if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
     }
     seg_steps = (nsteps + best - 1) / best;
     S = (nsteps + seg_steps - 1) / seg_steps;
+    workgroups = base * S;
+}
+
+// Waves per workgroup.  Eight waves share one B/C tile and one set of dB/dC atomics (half as many atomics per address as
+// two 4-wave workgroups) and win on short rows that fit the chip in one round (D 1024, L 320: 55 us with 8 waves, 73 us
+// with 4; D 640, L 1280: 96 vs 102 us).  Two independent 4-wave workgroups per CU win when a workgroup walks several
+// steps -- one runs while the other waits at its per-state barrier -- and past one round, where the last round is cut
+// finer (MI355X, cfg 2 grouped stages 0-3: 597/314/225/147 -> 583/293/198/145 us; cfg 3 stages 0-2:
+// 2241/1103/779 -> 2151/981/625 us).  vivim_set_tuning(1, 1 / 2) pins 8 / 4.
+struct BwdPlan { int W, S, seg_steps; };
+static BwdPlan bwd_plan(const vivim_ssm_fwd_params& f) {
+    BwdPlan q;
+    int64_t wgs = 0;
+    q.W = kBwWmax;
+    bwd_segmentation(f, q.W, q.S, q.seg_steps, wgs);
+    const int tv = tuning_bwd_variant();
+    if (tv == 2 || (tv != 1 && (wgs > device_cu_count() || q.seg_steps >= 4))) {
+        q.W = 4;
+        bwd_segmentation(f, q.W, q.S, q.seg_steps, wgs);
+    }
+    return q;
 }
 
 size_t scan_bwd_workspace_bytes(const vivim_ssm_fwd_params& f) {
     if (!f.is_variable_B || !f.is_variable_C || f.dstate > 64) return 0;
-    int S, seg_steps;
-    bwd_segmentation(f, S, seg_steps);
-    if (S <= 1) return 0;
-    return ((size_t)f.batch * f.dim * S * (2 * f.dstate + 1)) * sizeof(float);
+    const BwdPlan q = bwd_plan(f);
+    if (q.S <= 1) return 0;
+    return ((size_t)f.batch * f.dim * q.S * (2 * f.dstate + 1)) * sizeof(float);
 }
 
-template <typename T, int K, int MINW>
-static void launch_bwd_fast(const vivim_ssm_bwd_params& p, hipStream_t stream) {
+template <typename T, int K, int W>
+static void launch_bwd_fast(const vivim_ssm_bwd_params& p, const BwdPlan& plan, hipStream_t stream) {
     const vivim_ssm_fwd_params& f = p.f;
     const int cpg = f.dim / f.n_groups;
     const int ppg = (cpg + kBwR - 1) / kBwR;
-    const int bpg = (ppg + kBwW - 1) / kBwW;
+    const int bpg = (ppg + W - 1) / W;
     BwdSeg sg = {1, (f.seqlen + kWave * K - 1) / (kWave * K), nullptr, nullptr, nullptr};
     const size_t need = scan_bwd_workspace_bytes(f);
     if (need && p.workspace && (size_t)p.workspace_bytes >= need) {
-        bwd_segmentation(f, sg.S, sg.seg_steps);
+        sg.S = plan.S;
+        sg.seg_steps = plan.seg_steps;
         const size_t nbd = (size_t)f.batch * f.dim * sg.S;
         sg.agg = static_cast<float*>(p.workspace);
         sg.gin = sg.agg + nbd * f.dstate;
         sg.dsum = sg.gin + nbd * f.dstate;
     }
-    const dim3 block(kBwW * kWave);
-    // LDS: 2 slot buffers (32 KB) + records (N * 512 B) + per-lane dA partials when used (N * 4 KB): 104 KB at N = 16 --
-    // one workgroup per CU either way (register-bound already)
+    const dim3 block(W * kWave);
+    // LDS at W = 8: 2 slot buffers (32 KB) + records (N * 512 B) + per-lane dA partials when used (N * 4 KB): 104 KB at
+    // N = 16, half of that at W = 4 -- the registers (two waves per SIMD) bound the residency either way
     // per-lane dA partials in LDS pay off once a workgroup walks several steps (grouped stage 0, 6 steps: 724 -> 698 us);
     // for one or two steps their zero-fill and final reduction cost more than the per-state wave reductions they
     // replace (stage 3: 74 -> 80 us)
     const bool da_lds = f.dstate <= 16 && sg.seg_steps >= 2;
-    const size_t smem = ((size_t)2 * kBwW * 2 * K * kWave + (size_t)kBwW * f.dstate * kBwR * kRec +
-                         (da_lds ? (size_t)kBwW * f.dstate * kWave * 2 : 0)) * sizeof(float);
+    const size_t smem = ((size_t)2 * W * 2 * K * kWave + (size_t)W * f.dstate * kBwR * kRec +
+                         (da_lds ? (size_t)W * f.dstate * kWave * 2 : 0)) * sizeof(float);
     if (sg.S > 1) {
         const size_t per_wave = (size_t)f.dstate * kBwR * kWave * sizeof(float);            // 8 KB at N = 16, 32 KB at N = 64
         int nw = (int)((size_t)65536 / per_wave);
@@ -884,8 +906,8 @@ static void launch_bwd_fast(const vivim_ssm_bwd_params& p, hipStream_t stream) {
         }
         hipLaunchKernelGGL(kernel, grid, block, smem, stream, p, sg);
     };
-    if (f.z) { if (da_lds) launch(ssm_bwd_fast_kernel<T, K, true, MINW, true>); else launch(ssm_bwd_fast_kernel<T, K, true, MINW, false>); }
-    else     { if (da_lds) launch(ssm_bwd_fast_kernel<T, K, false, MINW, true>); else launch(ssm_bwd_fast_kernel<T, K, false, MINW, false>); }
+    if (f.z) { if (da_lds) launch(ssm_bwd_fast_kernel<T, K, true, W, true>); else launch(ssm_bwd_fast_kernel<T, K, true, W, false>); }
+    else     { if (da_lds) launch(ssm_bwd_fast_kernel<T, K, false, W, true>); else launch(ssm_bwd_fast_kernel<T, K, false, W, false>); }
 }
 
 template <typename T, int K>
@@ -908,14 +930,16 @@ static bool try_bwd_fast_k(const vivim_ssm_bwd_params& p, hipStream_t stream) {
                 !st(f.out_batch_stride) || !st(f.out_d_stride) || !st(p.dz_batch_stride) || !st(p.dz_d_stride) ||
                 (f.out_z && (!al(f.out_z) || !st(f.out_z_batch_stride) || !st(f.out_z_d_stride)))))
         return false;
-    // MINW = 2: registers uncapped (144-152 VGPRs at K = 4, 229-240 at K = 8; one 8-wave workgroup per CU, two waves per
-    // SIMD, 256 VGPRs available).  A 128-VGPR build of the K = 4 kernel (MINW = 4, two
+    // Two waves per SIMD (__launch_bounds__(W * 64, 2)): registers uncapped (144-152 VGPRs at K = 4, 229-248 at K = 8; one
+    // 8-wave or two 4-wave workgroups per CU, 256 VGPRs available).  A 128-VGPR build of the K = 4 kernel (four waves per SIMD, two
     // workgroups per CU) measured ~12% faster but needs 28-48 bytes of scratch per lane, and hipcc (ROCm 7.2) may
     // place such a VGPR spill at the top of the join block of a divergent loop, BEFORE the s_or_b64 that
     // restores EXEC: the store then runs with EXEC = 0, nothing is saved, and the reload returns garbage (seen as
     // wrong gradients and a GPU memory fault in fp32 once an unrelated edit changed the allocation).  No kernel
     // of this library may use scratch: `make check-scratch` (part of the default build) enforces it.
-    launch_bwd_fast<T, K, 2>(p, stream);
+    const BwdPlan plan = bwd_plan(f);
+    if (plan.W == 4) launch_bwd_fast<T, K, 4>(p, plan, stream);
+    else             launch_bwd_fast<T, K, kBwWmax>(p, plan, stream);
     return true;
 }
 
