@@ -107,8 +107,11 @@ def main():
         for k in a.kernels.split(","):
             t = timeit(runs[k], a.iters)
             nb = alg_bytes(k, B, D, L, N, s, G)
+            cut = ""
+            if k == "sb":      # segments of the token axis, from the workspace the backward asked for
+                cut = f"  S={ss.last_workspace_bytes.get('bwd', 0) // (B * D * (2 * N + 1) * 4) or 1}"
             print(f"  stage {st} D={D:5d} L={L:6d} {k}: {t * 1e6:9.1f} us  {nb / 1e6:8.1f} MB  {nb / t / 1e9:8.1f} GB/s "
-                  f"({nb / t / 8e12 * 100:5.1f}% of 8 TB/s)", flush=True)
+                  f"({nb / t / 8e12 * 100:5.1f}% of 8 TB/s){cut}", flush=True)
 
 
 if __name__ == "__main__":

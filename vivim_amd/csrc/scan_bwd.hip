@@ -286,7 +286,7 @@ template <int CTRL> __device__ __forceinline__ f2 dpp_mov2(f2 old, f2 src) {
 // DA_LDS (N <= 16): dA partial sums stay per lane in LDS and are reduced over the lanes once per segment, instead of
 // one wave reduction per (state, channel) and step.
 template <typename T, int K, bool HAS_Z, int W, bool DA_LDS>
-__global__ void __launch_bounds__(W * kWave, 2) ssm_bwd_fast_kernel(const vivim_ssm_bwd_params p, const BwdSeg sg) {
+__global__ void __launch_bounds__(W * kWave, (K == 4 && W == 4) ? 3 : 2) ssm_bwd_fast_kernel(const vivim_ssm_bwd_params p, const BwdSeg sg) {
     constexpr int R = kBwR;
     static_assert(R == 2, "the state loop is written on channel pairs");
     constexpr int TILE = kWave * K;
@@ -815,14 +815,16 @@ static void bwd_segmentation(const vivim_ssm_fwd_params& f, int W, int& S, int& 
     const int cpg = f.dim / f.n_groups;
     const int ppg = (cpg + kBwR - 1) / kBwR;
     const int64_t base = (int64_t)((ppg + W - 1) / W) * f.n_groups * f.batch;
-    const int slots = device_cu_count() * (kBwWmax / W);            // workgroups in flight: 8 waves per CU (240 VGPRs each)
+    // workgroups in flight per CU: two waves per SIMD at K = 8 (240-248 VGPRs), three at K = 4 with 4-wave workgroups (145)
+    const int slots = device_cu_count() * (tile == 4 * kWave && W == 4 ? 3 : kBwWmax / W);
     int best = 1;
     double best_cost = 1e300;
     for (int s = 1; s <= nsteps && s <= 64; ++s) {
         const int steps = (nsteps + s - 1) / s;
         if ((nsteps + steps - 1) / steps != s) continue;            // not a distinct cut
         const double rounds = (double)((base * s + slots - 1) / slots);
-        const double cost = rounds * (steps + 0.3);
+        // a cut adds the pre-pass over all segments but the first (~0.4 of a main-pass step per step) and the carry kernel
+        const double cost = rounds * (steps * (1.0 + 0.4 * (s - 1) / s) + 0.3);
         if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
     }
     seg_steps = (nsteps + best - 1) / best;

@@ -8,6 +8,7 @@ import torch
 from . import _lib
 
 _ITYPE = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}
+last_workspace_bytes = {}     # what the last fwd / bwd call asked for (tools/kbench.py derives the token-axis cut from it)
 
 
 def _check(cond, msg):
@@ -104,6 +105,7 @@ def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus):
         P.out_z = out_z.data_ptr()
         P.out_z_batch_stride, P.out_z_d_stride = out_z.stride(0), out_z.stride(1)
     ws_bytes = _lib.lib().vivim_scan_fwd_workspace_bytes(P)
+    last_workspace_bytes["fwd"] = ws_bytes
     if ws_bytes:
         workspace = _lib.empty((ws_bytes,), torch.uint8, u.device)
         P.workspace, P.workspace_bytes = workspace.data_ptr(), ws_bytes
@@ -180,6 +182,7 @@ def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softp
         P.dC_batch_stride, P.dC_group_stride, P.dC_dstate_stride = 0, dC.stride(0), dC.stride(1)
     P.dD, P.ddelta_bias = _ptr(dD), _ptr(ddelta_bias)
     ws_bytes = _lib.lib().vivim_scan_bwd_workspace_bytes(P.f)
+    last_workspace_bytes["bwd"] = ws_bytes
     if ws_bytes:
         workspace = _lib.empty((ws_bytes,), torch.uint8, u.device)   # torch caching allocator: no sync
         P.workspace, P.workspace_bytes = workspace.data_ptr(), ws_bytes
