@@ -80,7 +80,39 @@ def cpu_baseline(seconds_budget=12.0):
     return {"value": round(nbytes / best / 1e9, 5), "unit": "GB/s", "cores": cores, "kind": "port",
             "sample": f"selective_scan_ref port fwd, (B,D,N,L)=(1,{D},{N},{L}) fp32, {len(times)} calls in "
                       f"{sum(times):.1f} s, best {best:.2f} s (mean {mean:.2f} s) = {L / best:.0f} tokens/s on "
-                      f"{os.cpu_count()} host cpus"}
+                      f"{os.cpu_count()} host cpus",
+            "config1_mamba_forward": cpu_config1_mamba(ref_torch)}
+
+
+def cpu_config1_mamba(ref_torch):
+    """BASELINE.json configs[0] on the host CPUs, the Temporal-Mamba part: one clip, 256x256, clip_length 3, fp32, forward
+    only, through the v3 tri-directional Mamba module of each of the four stages (mamba_v3_forward_ref, the pure-PyTorch
+    composition of causal_conv1d_ref and selective_scan_ref); each stage is timed once and counted twice (depths
+    [2,2,2,2], modeling/vivim.py:165).  SegFormer and the MLPs are not part of it."""
+    import math
+    nf, img, N, expand = 3, 256, 16, 2
+    g = torch.Generator().manual_seed(1)
+    total, per_stage = 0.0, []
+    for dim, stride in zip((64, 128, 320, 512), (4, 8, 16, 32)):
+        d_in, R, L = expand * dim, math.ceil(dim / 16), nf * (img // stride) ** 2
+        rn = lambda *sh: torch.randn(*sh, generator=g)
+        p = {"in_proj.weight": rn(2 * d_in, dim) / math.sqrt(dim), "out_proj.weight": rn(dim, d_in) / math.sqrt(d_in)}
+        for sfx in ("", "_b", "_s"):
+            p[f"conv1d{sfx}.weight"], p[f"conv1d{sfx}.bias"] = rn(d_in, 1, 4) / 2, rn(d_in) / 10
+            p[f"x_proj{sfx}.weight"] = rn(R + 2 * N, d_in) / math.sqrt(d_in)
+            p[f"dt_proj{sfx}.weight"], p[f"dt_proj{sfx}.bias"] = rn(d_in, R) / math.sqrt(R), torch.full((d_in,), -4.0)
+            p[f"A{sfx}_log"] = torch.log(torch.arange(1, N + 1, dtype=torch.float32)).repeat(d_in, 1)
+            p[f"D{sfx}"] = torch.ones(d_in)
+        x = rn(1, L, dim)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            y = ref_torch.mamba_v3_forward_ref(x, p, nf)
+        dt = time.perf_counter() - t0
+        assert torch.isfinite(y).all()
+        per_stage.append(round(dt, 3))
+        total += 2 * dt
+    return {"seconds_per_clip": round(total, 3), "frames_per_s": round(nf / total, 3), "stage_seconds": per_stage,
+            "what": "8 v3 Mamba modules (4 stages x 2) of one 256x256 clip of 3 frames, fp32 forward, pure-PyTorch reference port"}
 
 
 def measured_copy_ceiling(dev, nbytes=1 << 30, iters=10):
