@@ -63,35 +63,16 @@ __global__ void __launch_bounds__(256) ssm_fwd_bc_kernel(const vivim_ssm_fwd_par
     }
 }
 
-// ---- the per-token state update, hand-scheduled ---------------------------------------------------------------
+// ---- the per-token state update --------------------------------------------------------------------------------
 // 16 states of one token: a = exp2(dl*A2); h = a*h + (w*B); y += h*C  with B, C as SGPR operands.
 // Two FIXED scalar sets ping-pong, each one whole BC row [B0-7 | C0-7 | B8-15 | C8-15]: X = s[68:99], Y = s[36:67].
-// A token is two asm statements (the operand limit is 30): the first issues BOTH loads of the row the NEXT token
-// consumes and computes states 0-7 from its own set, the second computes states 8-15 and ends with
-// s_waitcnt lgkmcnt(0).  Scalar loads return out of order, so every wait on them is lgkmcnt(0): one wait per token, a
-// whole token of work (~90 VALU instructions) between issue and wait.  (The first version waited per HALF token: the
-// SQ counters showed the waves parked 42 % of the time.)  Nothing of ours is in flight between tokens, so the
-// compiler's own waits never drain a prefetch early.  The kernel is compiled with amdgpu_num_sgpr(kChSgprLimit): the
-// compiler never allocates s[36:99] itself, so the sets survive the compiler-generated code between the statements
-// (register allocation kept spilling the scalar sets to VGPR lanes inside the hot loop when this was plain C++).
-#define CH_S4(i0, i1, i2, i3, B0, B1, B2, B3)                                                   \
-    "v_mul_f32 %[t0], %[dl], %[a" #i0 "]\n\tv_mul_f32 %[t1], %[dl], %[a" #i1 "]\n\t"            \
-    "v_mul_f32 %[t2], %[dl], %[a" #i2 "]\n\tv_mul_f32 %[t3], %[dl], %[a" #i3 "]\n\t"            \
-    "v_exp_f32 %[t0], %[t0]\n\tv_exp_f32 %[t1], %[t1]\n\t"                                      \
-    "v_exp_f32 %[t2], %[t2]\n\tv_exp_f32 %[t3], %[t3]\n\t"                                      \
-    "v_mul_f32 %[u0], " #B0 ", %[w]\n\tv_mul_f32 %[u1], " #B1 ", %[w]\n\t"                      \
-    "v_mul_f32 %[u2], " #B2 ", %[w]\n\tv_mul_f32 %[u3], " #B3 ", %[w]\n\t"                      \
-    "v_fma_f32 %[h" #i0 "], %[t0], %[h" #i0 "], %[u0]\n\tv_fma_f32 %[h" #i1 "], %[t1], %[h" #i1 "], %[u1]\n\t" \
-    "v_fma_f32 %[h" #i2 "], %[t2], %[h" #i2 "], %[u2]\n\tv_fma_f32 %[h" #i3 "], %[t3], %[h" #i3 "], %[u3]\n\t"
-#define CH_Y4(i0, i1, i2, i3, C0, C1, C2, C3)                                                   \
-    "v_fma_f32 %[y0], %[h" #i0 "], " #C0 ", %[y0]\n\tv_fma_f32 %[y1], %[h" #i1 "], " #C1 ", %[y1]\n\t" \
-    "v_fma_f32 %[y0], %[h" #i2 "], " #C2 ", %[y0]\n\tv_fma_f32 %[y1], %[h" #i3 "], " #C3 ", %[y1]\n\t"
-#define CH_OPERANDS(hp, ap)                                                                                    \
-    : [h0] "+v"(hp[0]), [h1] "+v"(hp[1]), [h2] "+v"(hp[2]), [h3] "+v"(hp[3]), [h4] "+v"(hp[4]), [h5] "+v"(hp[5]), \
-      [h6] "+v"(hp[6]), [h7] "+v"(hp[7]), [y0] "+v"(y0), [y1] "+v"(y1), [t0] "=&v"(t0), [t1] "=&v"(t1),          \
-      [t2] "=&v"(t2), [t3] "=&v"(t3), [u0] "=&v"(u0), [u1] "=&v"(u1), [u2] "=&v"(u2), [u3] "=&v"(u3)             \
-    : [a0] "v"(ap[0]), [a1] "v"(ap[1]), [a2] "v"(ap[2]), [a3] "v"(ap[3]), [a4] "v"(ap[4]), [a5] "v"(ap[5]),      \
-      [a6] "v"(ap[6]), [a7] "v"(ap[7]), [dl] "v"(dl), [w] "v"(w), [ptr] "s"(next)
+// A token first issues BOTH loads of the row the NEXT token consumes (into the other set), computes its 16 states from
+// its own set and ends with s_waitcnt lgkmcnt(0).  Scalar loads return out of order, so every wait on them is
+// lgkmcnt(0): one wait per token, a whole token of work between issue and wait.  (The first version waited per HALF
+// token: the SQ counters showed the waves parked 42 % of the time.)  The kernel is compiled with
+// amdgpu_num_sgpr(kChSgprLimit): the compiler never allocates s[36:99] itself, so the sets survive the
+// compiler-generated code around the asm statements (register allocation kept spilling the scalar sets to VGPR lanes
+// inside the hot loop when B and C were plain C++ values).
 #define CH_CLOB                                                                                                  \
     "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",  \
     "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67",  \
@@ -110,54 +91,61 @@ constexpr int kChSgprLimit = 40;   // advisory: the compiler peaks at s39 (tile 
 #define CH_LOAD_Y1 "s_load_dwordx8 s[36:43], %[ptr], 0x0\n\ts_load_dwordx8 s[52:59], %[ptr], 0x40\n\t"
 #define CH_LOAD_X1 "s_load_dwordx8 s[68:75], %[ptr], 0x0\n\ts_load_dwordx8 s[84:91], %[ptr], 0x40\n\t"
 
-// states 0-7 of the token whose row is in X; issues the loads of `next` (the following token's row) into Y
+// ---- state pairs on v_pk_*_f32 ----------------------------------------------------------------------------------
+// The arithmetic of a state pair (2n, 2n+1) is  t = dl * A2 (pk_mul), two v_exp_f32, u = B * w (pk_mul, B an SGPR pair),
+// h = t * h + u (pk_fma), y += h * C (pk_fma, C an SGPR pair): 6 instructions for two state updates (the first version
+// spent 10 scalar ones inside two 40-instruction asm blocks per token; same roundings in the same order -- y.x collects
+// the even states, y.y the odd ones -- so the results did not change by a bit).  Only the two instructions that name the
+// fixed scalar registers are inline asm (an asm operand cannot name one half of a 64-bit register pair, which the
+// v_exp_f32 pair would need); the rest is C++ on 2-vectors, which hipcc maps to v_pk_mul/fma_f32 with op_sel broadcasts
+// and interleaves across the eight pairs.  All asm statements are volatile, so they keep their order among themselves:
+// a set is never read before the wait that completes it nor after the load that overwrites it.
+// Measured: 40 % fewer VALU instructions per token bought only 2-5 % (cfg 3 stage 0: 1005 -> 954 us, grouped 2745 ->
+// 2610 us): on this chip a v_pk_fma_f32 occupies the issue port as long as the two v_fma_f32 it replaces.
+typedef float cf2 __attribute__((ext_vector_type(2)));
+#define CHP_PAIR(j, BP, CP)                                                                        \
+    {                                                                                              \
+        cf2 t = dlp * ap[j];                                                                       \
+        t.x = fast_exp2(t.x);                                                                      \
+        t.y = fast_exp2(t.y);                                                                      \
+        cf2 u;                                                                                     \
+        asm volatile("v_pk_mul_f32 %0, " BP ", %1" : "=v"(u) : "v"(wp));                           \
+        hp[j] = __builtin_elementwise_fma(t, hp[j], u);                                            \
+        if (PASS == 2) asm volatile("v_pk_fma_f32 %0, %1, " CP ", %0" : "+v"(y2) : "v"(hp[j]));    \
+    }
+#define CH_CLOB_Y                                                                                                \
+    "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",  \
+    "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67"
+#define CH_CLOB_X                                                                                                \
+    "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83",  \
+    "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
+
+// one token whose row is in X (s[68:99]); issues the loads of `next` (the following token's row) into Y first and waits
+// for them after the token's last instruction.  hp / ap: the 8 state pairs and their A * log2e.
 template <int PASS>
-__device__ __forceinline__ void chan_lo_x(float* hp, const float* ap, float dl, float w, float& y0, float& y1, const float* next) {
-    float t0, t1, t2, t3, u0, u1, u2, u3;
-    if (PASS == 2)
-        asm volatile("; CHAN lo_x\n\t" CH_LOAD_Y2 CH_S4(0, 1, 2, 3, s68, s69, s70, s71) CH_S4(4, 5, 6, 7, s72, s73, s74, s75)
-                     CH_Y4(0, 1, 2, 3, s76, s77, s78, s79) CH_Y4(4, 5, 6, 7, s80, s81, s82, s83) "s_nop 0"
-                     CH_OPERANDS(hp, ap) : CH_CLOB);
-    else
-        asm volatile("; CHAN lo_x\n\t" CH_LOAD_Y1 CH_S4(0, 1, 2, 3, s68, s69, s70, s71) CH_S4(4, 5, 6, 7, s72, s73, s74, s75) "s_nop 0"
-                     CH_OPERANDS(hp, ap) : CH_CLOB);
+__device__ __forceinline__ void chan_token_x(cf2* hp, const cf2* ap, float dl, float w, cf2& y2, const float* next) {
+    const cf2 dlp = {dl, dl}, wp = {w, w};
+    if (PASS == 2) asm volatile("; CHAN lo_x\n\t" CH_LOAD_Y2 : : [ptr] "s"(next) : CH_CLOB_Y);
+    else           asm volatile("; CHAN lo_x\n\t" CH_LOAD_Y1 : : [ptr] "s"(next) : CH_CLOB_Y);
+    CHP_PAIR(0, "s[68:69]", "s[76:77]") CHP_PAIR(1, "s[70:71]", "s[78:79]")
+    CHP_PAIR(2, "s[72:73]", "s[80:81]") CHP_PAIR(3, "s[74:75]", "s[82:83]")
+    CHP_PAIR(4, "s[84:85]", "s[92:93]") CHP_PAIR(5, "s[86:87]", "s[94:95]")
+    CHP_PAIR(6, "s[88:89]", "s[96:97]") CHP_PAIR(7, "s[90:91]", "s[98:99]")
+    asm volatile("; CHAN hi_x\n\ts_waitcnt lgkmcnt(0)");
 }
-// states 8-15 of the token whose row is in X; then waits for the loads issued by chan_lo_x
+// the same for a token whose row is in Y (s[36:67]); loads the following row into X
 template <int PASS>
-__device__ __forceinline__ void chan_hi_x(float* hp, const float* ap, float dl, float w, float& y0, float& y1) {
-    float t0, t1, t2, t3, u0, u1, u2, u3;
-    const float* next = nullptr;
-    if (PASS == 2)
-        asm volatile("; CHAN hi_x\n\t" CH_S4(0, 1, 2, 3, s84, s85, s86, s87) CH_S4(4, 5, 6, 7, s88, s89, s90, s91)
-                     CH_Y4(0, 1, 2, 3, s92, s93, s94, s95) CH_Y4(4, 5, 6, 7, s96, s97, s98, s99) "s_waitcnt lgkmcnt(0)"
-                     CH_OPERANDS(hp, ap) : CH_CLOB);
-    else
-        asm volatile("; CHAN hi_x\n\t" CH_S4(0, 1, 2, 3, s84, s85, s86, s87) CH_S4(4, 5, 6, 7, s88, s89, s90, s91) "s_waitcnt lgkmcnt(0)"
-                     CH_OPERANDS(hp, ap) : CH_CLOB);
+__device__ __forceinline__ void chan_token_y(cf2* hp, const cf2* ap, float dl, float w, cf2& y2, const float* next) {
+    const cf2 dlp = {dl, dl}, wp = {w, w};
+    if (PASS == 2) asm volatile("; CHAN lo_y\n\t" CH_LOAD_X2 : : [ptr] "s"(next) : CH_CLOB_X);
+    else           asm volatile("; CHAN lo_y\n\t" CH_LOAD_X1 : : [ptr] "s"(next) : CH_CLOB_X);
+    CHP_PAIR(0, "s[36:37]", "s[44:45]") CHP_PAIR(1, "s[38:39]", "s[46:47]")
+    CHP_PAIR(2, "s[40:41]", "s[48:49]") CHP_PAIR(3, "s[42:43]", "s[50:51]")
+    CHP_PAIR(4, "s[52:53]", "s[60:61]") CHP_PAIR(5, "s[54:55]", "s[62:63]")
+    CHP_PAIR(6, "s[56:57]", "s[64:65]") CHP_PAIR(7, "s[58:59]", "s[66:67]")
+    asm volatile("; CHAN hi_y\n\ts_waitcnt lgkmcnt(0)");
 }
-template <int PASS>
-__device__ __forceinline__ void chan_lo_y(float* hp, const float* ap, float dl, float w, float& y0, float& y1, const float* next) {
-    float t0, t1, t2, t3, u0, u1, u2, u3;
-    if (PASS == 2)
-        asm volatile("; CHAN lo_y\n\t" CH_LOAD_X2 CH_S4(0, 1, 2, 3, s36, s37, s38, s39) CH_S4(4, 5, 6, 7, s40, s41, s42, s43)
-                     CH_Y4(0, 1, 2, 3, s44, s45, s46, s47) CH_Y4(4, 5, 6, 7, s48, s49, s50, s51) "s_nop 0"
-                     CH_OPERANDS(hp, ap) : CH_CLOB);
-    else
-        asm volatile("; CHAN lo_y\n\t" CH_LOAD_X1 CH_S4(0, 1, 2, 3, s36, s37, s38, s39) CH_S4(4, 5, 6, 7, s40, s41, s42, s43) "s_nop 0"
-                     CH_OPERANDS(hp, ap) : CH_CLOB);
-}
-template <int PASS>
-__device__ __forceinline__ void chan_hi_y(float* hp, const float* ap, float dl, float w, float& y0, float& y1) {
-    float t0, t1, t2, t3, u0, u1, u2, u3;
-    const float* next = nullptr;
-    if (PASS == 2)
-        asm volatile("; CHAN hi_y\n\t" CH_S4(0, 1, 2, 3, s52, s53, s54, s55) CH_S4(4, 5, 6, 7, s56, s57, s58, s59)
-                     CH_Y4(0, 1, 2, 3, s60, s61, s62, s63) CH_Y4(4, 5, 6, 7, s64, s65, s66, s67) "s_waitcnt lgkmcnt(0)"
-                     CH_OPERANDS(hp, ap) : CH_CLOB);
-    else
-        asm volatile("; CHAN hi_y\n\t" CH_S4(0, 1, 2, 3, s52, s53, s54, s55) CH_S4(4, 5, 6, 7, s56, s57, s58, s59) "s_waitcnt lgkmcnt(0)"
-                     CH_OPERANDS(hp, ap) : CH_CLOB);
-}
+
 // the first row of a segment into X
 template <int PASS>
 __device__ __forceinline__ void chan_prime_x(const float* next) {
@@ -210,13 +198,14 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
     unsigned char* tile_d = lds + (wave * NARR + 1) * kWave * ROWB;
     unsigned char* tile_z = lds + (wave * NARR + (NARR - 1)) * kWave * ROWB;   // only used when NARR == 3
 
-    float A2[N], h[N];
+    cf2 A2p[N / 2], hp[N / 2];                        // state pairs (2j, 2j + 1)
     {
         const float* __restrict__ A = static_cast<const float*>(p.A);
 #pragma unroll
         for (int n = 0; n < N; ++n) {
-            A2[n] = A[d * p.A_d_stride + n * p.A_dstate_stride] * kLog2e;     // fwd_kernel.cuh:168-175
-            h[n] = (PASS == 2 && seg > 0) ? sg.H[(((int64_t)b * p.dim + d) * sg.S + seg) * N + n] : 0.0f;
+            const float a2 = A[d * p.A_d_stride + n * p.A_dstate_stride] * kLog2e;     // fwd_kernel.cuh:168-175
+            const float h0 = (PASS == 2 && seg > 0) ? sg.H[(((int64_t)b * p.dim + d) * sg.S + seg) * N + n] : 0.0f;
+            if (n & 1) { A2p[n / 2].y = a2; hp[n / 2].y = h0; } else { A2p[n / 2].x = a2; hp[n / 2].x = h0; }
         }
     }
     const float Dv = p.D ? static_cast<const float*>(p.D)[d] : 0.0f;
@@ -313,14 +302,12 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
             const float* bct = bc + (int64_t)tb * 32;     // uniform: this block's first BC row
 #pragma unroll
             for (int k = 0; k < TB; k += 2) {             // tokens alternate between the two scalar sets
-                float y1 = 0.0f;
-                chan_lo_x<PASS>(h, A2, dl[k], w[k], yo[k], y1, bct + (k + 1) * 32);           // prefetch: token k + 1 -> Y
-                chan_hi_x<PASS>(h + 8, A2 + 8, dl[k], w[k], yo[k], y1);
-                if (PASS == 2) yo[k] += y1;
-                y1 = 0.0f;
-                chan_lo_y<PASS>(h, A2, dl[k + 1], w[k + 1], yo[k + 1], y1, bct + (k + 2) * 32);   // token k + 2 -> X
-                chan_hi_y<PASS>(h + 8, A2 + 8, dl[k + 1], w[k + 1], yo[k + 1], y1);
-                if (PASS == 2) yo[k + 1] += y1;
+                cf2 y2 = {yo[k], 0.0f};
+                chan_token_x<PASS>(hp, A2p, dl[k], w[k], y2, bct + (k + 1) * 32);             // prefetch: token k + 1 -> Y
+                if (PASS == 2) yo[k] = y2.x + y2.y;
+                y2 = cf2{yo[k + 1], 0.0f};
+                chan_token_y<PASS>(hp, A2p, dl[k + 1], w[k + 1], y2, bct + (k + 2) * 32);     // token k + 2 -> X
+                if (PASS == 2) yo[k + 1] = y2.x + y2.y;
             }
             if (PASS == 2) {
                 // state after every kChunk tokens and after the last one: always the last token of a block
@@ -328,7 +315,7 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
                 if (((tl + 1) & (kChunk - 1)) == 0 || tl == L - 1) {
                     float* xr = xlane + (tl / kChunk) * N;
 #pragma unroll
-                    for (int n = 0; n < N; ++n) xr[n] = h[n];
+                    for (int n = 0; n < N; ++n) xr[n] = (n & 1) ? hp[n / 2].y : hp[n / 2].x;
                 }
                 // results overwrite the lane's own consumed input columns
                 union { T e[TB]; vblk v; } co, cz;
@@ -372,7 +359,7 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
     if (PASS == 1) {
         float* Hs = sg.H + (((int64_t)b * p.dim + d) * sg.S + seg) * N;
 #pragma unroll
-        for (int n = 0; n < N; ++n) Hs[n] = h[n];
+        for (int n = 0; n < N; ++n) Hs[n] = (n & 1) ? hp[n / 2].y : hp[n / 2].x;
         sg.dsum[((int64_t)b * p.dim + d) * sg.S + seg] = dsum;
     }
 }
@@ -430,7 +417,8 @@ static void fwd_chan_segmentation(const vivim_ssm_fwd_params& f, int tt, int& S,
     const int cpg = f.dim / f.n_groups;
     const int64_t waves = (int64_t)((cpg + kWave - 1) / kWave) * f.n_groups * f.batch;
     // 2048 waves: swept 512 ... 8192 on the grouped cfg-2 shapes (309/144/106/64 us at 2048; 377/198/130/68 at 1024;
-    // 320/167/125/70 at 4096)
+    // 320/167/125/70 at 4096); again with the packed token update: 293/146/101/69 at 1536, 283/141/104/70 at 2048,
+    // 300/164/115/70 at 3072, 304/165/124/70 at 4096
     int64_t want = (2048 + waves - 1) / waves;
     if (want > ntiles) want = ntiles;
     if (want > 512) want = 512;       // the carry kernel keeps a whole chain in LDS: 512 * 17 * 4 = 34 KB
