@@ -33,6 +33,17 @@ __global__ void __launch_bounds__(256) k_valu(float* out, int iters) {
         if (MODE == 2) { a0 = fmaf(a0, 0.999f, 0.1f); a0 = fmaf(a0, 0.999f, 0.1f); a0 = fmaf(a0, 0.999f, 0.1f); a0 = fmaf(a0, 0.999f, 0.1f);
                          a0 = fmaf(a0, 0.999f, 0.1f); a0 = fmaf(a0, 0.999f, 0.1f); a0 = fmaf(a0, 0.999f, 0.1f); a0 = fmaf(a0, 0.999f, 0.1f); }   // dependent chain
     }
+    if (MODE == 3) {      // the same eight chains as four packed pairs: one v_pk_fma_f32 does the work of two v_fma_f32
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7};
+        const f2 m = {0.999f, 0.999f}, c = {0.1f, 0.1f};
+        for (int it = 0; it < iters; ++it) {
+            p0 = __builtin_elementwise_fma(p0, m, c); p1 = __builtin_elementwise_fma(p1, m, c);
+            p2 = __builtin_elementwise_fma(p2, m, c); p3 = __builtin_elementwise_fma(p3, m, c);
+            asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));      // keep them packed and in the loop
+        }
+        a0 = p0.x; a1 = p0.y; a2 = p1.x; a3 = p1.y; a4 = p2.x; a5 = p2.y; a6 = p3.x; a7 = p3.y;
+    }
     out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
 }
 template <typename F> float timeit(F f) {
@@ -54,8 +65,11 @@ int main() {
         float m0 = timeit([&] { hipLaunchKernelGGL(k_valu<0>, dim3(256 * wpb), dim3(256), 0, 0, out, it2); });
         float m1 = timeit([&] { hipLaunchKernelGGL(k_valu<1>, dim3(256 * wpb), dim3(256), 0, 0, out, it2); });
         float m2 = timeit([&] { hipLaunchKernelGGL(k_valu<2>, dim3(256 * wpb), dim3(256), 0, 0, out, it2); });
-        printf("%d wave(s)/SIMD: v_exp_f32 %.2f cyc/instr/SIMD, independent fma %.2f, dependent fma chain %.2f\n", wpb,
-               m0 * 1e-3 * clk / (it2 * 8.0 * wpb), m1 * 1e-3 * clk / (it2 * 8.0 * wpb), m2 * 1e-3 * clk / (it2 * 8.0 * wpb));
+        float m3 = timeit([&] { hipLaunchKernelGGL(k_valu<3>, dim3(256 * wpb), dim3(256), 0, 0, out, it2); });
+        printf("%d wave(s)/SIMD: v_exp_f32 %.2f cyc/instr/SIMD, independent fma %.2f, dependent fma chain %.2f, v_pk_fma_f32 %.2f "
+               "(= %.2f per fma it replaces)\n", wpb,
+               m0 * 1e-3 * clk / (it2 * 8.0 * wpb), m1 * 1e-3 * clk / (it2 * 8.0 * wpb), m2 * 1e-3 * clk / (it2 * 8.0 * wpb),
+               m3 * 1e-3 * clk / (it2 * 4.0 * wpb), m3 * 1e-3 * clk / (it2 * 8.0 * wpb));
     }
     return 0;
 }
