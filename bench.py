@@ -148,6 +148,11 @@ def pmc_traffic(entry_point):
 
 def main():
     a = parse()
+    # stdout carries the ONE result line and nothing else: RCCL prints a version banner to fd 1 when the first
+    # communicator comes up, other libraries may do the same.  Everything else goes to stderr.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     from vivim_amd import _lib, dp
     from vivim_amd.train_step import build_model, make_optimizer, synthetic_batch, train_step
     world, rank, local_rank = dp.dist_env()
@@ -229,7 +234,8 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()
 
