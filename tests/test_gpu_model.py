@@ -242,3 +242,28 @@ def test_train_trajectory_grouped_equals_separate(cuda, monkeypatch):
         del model, opt
     for a, b in zip(losses["0"], losses["1"]):
         assert abs(a - b) <= 5e-3 * abs(b), (losses["0"], losses["1"])
+
+
+@pytest.mark.gpu
+def test_lean_adamw_equals_torch_fused_adamw(cuda):
+    """train_step.LeanFusedAdamW drives the same fused kernel as torch.optim.AdamW(fused=True) with cached lists:
+    identical parameters after several steps, including a step in which one parameter has no gradient."""
+    from vivim_amd.train_step import LeanFusedAdamW
+    g = torch.Generator().manual_seed(5)
+    shapes = [(64, 32), (7,), (3, 5, 2), (1,), (128, 128)]
+    pa = [torch.randn(*s, generator=g).to(cuda).requires_grad_(True) for s in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    oa = LeanFusedAdamW(pa, lr=1e-2, betas=(0.9, 0.999), weight_decay=1e-2)
+    ob = torch.optim.AdamW(pb, lr=1e-2, betas=(0.9, 0.999), weight_decay=1e-2, fused=True)
+    for step in range(5):
+        grads = [torch.randn(*s, generator=g).to(cuda) for s in shapes]
+        for i, (a, b, gr) in enumerate(zip(pa, pb, grads)):
+            skip = step == 2 and i == 1
+            a.grad = None if skip else gr.clone()
+            b.grad = None if skip else gr.clone()
+        oa.step()
+        ob.step()
+        oa.zero_grad()
+        ob.zero_grad(set_to_none=True)
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b)
