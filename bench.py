@@ -47,7 +47,8 @@ def parse():
     ap.add_argument("--expand", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stock-backbone-dwconv", action="store_true",
-                    help="leave the SegFormer Mix-FFN depthwise convs on MIOpen instead of csrc/dwconv.hip")
+                    help="leave the SegFormer blocks stock: Mix-FFN depthwise convs on MIOpen instead of csrc/dwconv.hip, "
+                         "transformers' own DropPath")
     return ap.parse_args()
 
 

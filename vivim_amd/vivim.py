@@ -14,7 +14,7 @@ Differences from the reference, all additive:
     layer_norm` + `decode_head.linear_c`, and 5.x `stages[i].{patch_embeddings,blocks,layer_norm}` +
     `decode_head.linear_projections`).
   * the Mlp's depthwise Conv3d runs on the token-major HIP kernel (csrc/dwconv.hip) when the
-    tensor qualifies; `fast_backbone_dwconv=True` additionally routes the SegFormer Mix-FFN 3x3 depthwise convs
+    tensor qualifies; `fast_backbone_dwconv=True` swaps the SegFormer blocks' DropPath for the one-kernel form and routes the SegFormer Mix-FFN 3x3 depthwise convs
     through the same kernel (same parameters, same math, state-dict keys unchanged).
   * timm is not required: DropPath / trunc_normal_ are the torch equivalents.
 """
@@ -41,8 +41,10 @@ class DropPath(nn.Module):
         if self.drop_prob == 0.0 or not self.training:
             return x
         keep = 1.0 - self.drop_prob
-        mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
-        return x * mask / keep
+        # timm: random_tensor.bernoulli_(keep).div_(keep); x * random_tensor -- the scaling stays on the (B, 1, ...) mask,
+        # the activation is touched by ONE elementwise kernel forward and one backward
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep).div_(keep)
+        return x * mask
 
 
 def _init_weights(m):
@@ -181,6 +183,20 @@ def _swap_backbone_dwconv(module):
     return n
 
 
+def _swap_backbone_droppath(module):
+    """Replace the SegFormer blocks' stochastic-depth modules (transformers' SegformerDropPath: rand, add, floor on the
+    mask, then a full-size div and a full-size mul) by `DropPath` above: the same keep/drop distribution and scaling with
+    one full-size kernel instead of two and three launches instead of five (58 of them per step forward, and again
+    backward, in a step whose critical path is the host)."""
+    n = 0
+    for m in module.modules():
+        dp = getattr(m, "drop_path", None)
+        if isinstance(dp, nn.Module) and type(dp).__name__ == "SegformerDropPath":
+            m.drop_path = DropPath(float(dp.drop_prob))
+            n += 1
+    return n
+
+
 class _Encoder(nn.Module):
     """Holds the SegFormer encoder pieces under the reference's attribute names."""
 
@@ -207,6 +223,7 @@ class mamba_block(nn.Module):
         self.downsample_layers = _Encoder(backbone)
         if fast_backbone_dwconv:
             _swap_backbone_dwconv(self.downsample_layers)
+            _swap_backbone_droppath(self.downsample_layers)
         dp_rates = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths))]
         mk = mamba_kwargs or {}
         self.stages = nn.ModuleList()
