@@ -93,8 +93,10 @@ def causal_conv1d_bwd(x, weight, bias_, dout, dx_, silu_activation):
             dx = _lib.empty_like(x)
             if dx.stride(2) != 1:
                 dx = _lib.empty(tuple(x.shape), x.dtype, x.device)
-    dweight = torch.zeros(weight.shape, device=x.device, dtype=torch.float32)
-    dbias = torch.zeros(dim, device=x.device, dtype=torch.float32) if bias_ is not None else None
+    nw = dim * width                                  # one zero-filled fp32 accumulator for dweight | dbias: one fill
+    acc = torch.zeros(nw + (dim if bias_ is not None else 0), device=x.device, dtype=torch.float32)
+    dweight = acc[:nw].view(dim, width)
+    dbias = acc[nw:] if bias_ is not None else None
     P = _lib.ConvBwdParams()
     _fill(P.f, x, weight, bias_, silu_activation, dims)
     P.dout, P.dx, P.dweight = dout.data_ptr(), dx.data_ptr(), dweight.data_ptr()
