@@ -1,6 +1,7 @@
 """The v3 block's directional index maps as two HIP kernels (csrc/dirmap.hip; include/vivim_hip.h: vivim_dir_params).
 
-    stack_directions(xz, nframes)      (B, 2D, L) -> (B, 2, 3, D, L): [.., 0] = xz, [.., 1] = xz.flip(-1),
+    stack_directions(xz, nframes)      (B, 2D, L) -> (B, 2, 3, D, L) (channel-major in memory, see _scatter):
+                                       [.., 0] = xz, [.., 1] = xz.flip(-1),
                                        [.., 2] = the frame interleave t*hw+p -> p*nf+t   (mamba_simple.py:231, 245-247)
     combine_directions(o3, nframes)    (B, 3, D, L) -> (B, D, L): (o3[:,0] + o3[:,1].flip(-1) + interleave^-1(o3[:,2])) / 3
                                        (mamba_simple.py:261-264)
@@ -24,11 +25,14 @@ def _params(flat, stacked, nframes, csplit, scale, src, dst):
 
 
 def _scatter(flat, nframes, csplit, scale):
-    """flat (B, C, L), unit L stride -> stacked (B, C / csplit, 3, csplit, L) contiguous."""
+    """flat (B, C, L), unit L stride -> stacked (B, C / csplit, 3, csplit, L), CHANNEL-major in memory: the buffer is
+    (C / csplit, 3, csplit, B, L) and the result its permuted view (batch stride L).  The fused grouped op multiplies
+    all clips of a direction by that direction's weights in one GEMM over (channels) x (B * L) -- which needs the
+    channel axis outermost -- and every kernel behind the C ABI takes batch / channel strides as they come."""
     if flat.stride(-1) != 1:
         flat = flat.contiguous()
     B, C, L = flat.shape
-    stacked = _lib.empty((B, C // csplit, 3, csplit, L), flat.dtype, flat.device)
+    stacked = _lib.empty((C // csplit, 3, csplit, B, L), flat.dtype, flat.device).permute(3, 0, 1, 2, 4)
     with torch.cuda.device(flat.device):
         _lib.call("vivim_dir_scatter", _params(flat, stacked, nframes, csplit, scale, flat, stacked),
                   torch.cuda.current_stream().cuda_stream)

@@ -185,58 +185,70 @@ def mamba_inner_fn_no_out_proj(xz, conv1d_weight, conv1d_bias, x_proj_weight, de
                                        A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus)
 
 
+def _channel_major(t):
+    """(batch, C, l) -> the same values laid out (C, batch, l) in memory, returned as the (batch, C, l) view with strides
+    (l, batch*l, 1).  A no-op for tensors that already are (Vivim's xz, everything the grouped op allocates)."""
+    b, c, l = t.shape
+    if t.stride() == (l, b * l, 1) or b == 1 and t.stride(2) == 1 and t.stride(1) == l:
+        return t
+    return t.permute(1, 0, 2).contiguous().permute(1, 0, 2)
+
+
 class MambaInnerGroupedFnNoOutProj(torch.autograd.Function):
     """G independent `MambaInnerFnNoOutProj` problems (Vivim: the three scan directions of one v3 block, each with
     its own conv / x_proj / dt_proj / A / D) as ONE autograd node: the directions are laid side by side on the
     channel axis, so there is one conv1d launch over G*D channels and one scan launch with n_groups = G instead of
-    G of each, and G times more independent work per launch.  The projections run as batched GEMMs in the
-    orientation  x_dbl^T = W_x @ conv_out  (per batch element and direction), which leaves B and C as (b, G, N, l)
-    views with unit l-stride -- the `(b l) N -> b 1 N l` transpose copies of the single-direction op (reference
-    :193, :205) and the transposed copy of conv_out for `F.linear` (:181) are gone.  Same math, same saved-tensor
-    policy (conv_out and delta are rebuilt in the backward, checkpoint_lvl = 1).
+    G of each, and G times more independent work per launch.
 
-    xz:   (batch, 2, G, D, l) contiguous -- [:, 0] the x halves, [:, 1] the z halves of the G directions
+    Everything inside is CHANNEL-major: conv_out, delta, x_dbl live as (G, D | R+2N, batch*l), i.e. the (batch, C, l) views
+    the kernels see have strides (l, batch*l, 1) -- the layout of Vivim's own xz (mamba_simple.py:204-208).  Each
+    projection is then ONE batched GEMM over the G directions with all clips in its N dimension,
+    x_dbl = W_x @ conv_out: no per-clip weight replication, weight gradients summed over the clips inside the GEMM's fp32
+    accumulator, and B / C are (b, G, N, l) VIEWS of x_dbl with unit l-stride -- the `(b l) N -> b 1 N l` transpose copies
+    of the single-direction op (reference :193, :205) and the transposed copy of conv_out for `F.linear` (:181) are gone.
+    Same math, same saved-tensor policy (conv_out and delta are rebuilt in the backward, checkpoint_lvl = 1).
+
+    xz:   (batch, 2, G, D, l), unit l stride -- [:, 0] the x halves, [:, 1] the z halves of the G directions; channel-major
+          as `dirmap.stack_directions` makes it (any other layout is re-laid once)
     conv1d_weight (G*D, W), conv1d_bias (G*D) | x_proj_weight (G, R + 2N, D) | delta_proj_weight (G, D, R)
     A (G*D, N) fp32 | D (G*D) fp32 | delta_bias (G*D) fp32            ->  out_z (batch, G*D, l)
     """
+
+    @staticmethod
+    def _cm(t, G):
+        """(batch, G*D, l) with strides (l, batch*l, 1) -> (G, D, batch*l) view."""
+        b, c, l = t.shape
+        return t.permute(1, 0, 2).reshape(G, c // G, b * l)
 
     @staticmethod
     @custom_fwd(device_type="cuda")
     def forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias,
                 delta_softplus=True):
         batch, two, G, Dm, L = xz.shape
-        assert two == 2 and xz.is_contiguous()
+        assert two == 2
         R = delta_proj_weight.shape[2]
         N = A.shape[-1]
         if torch.is_autocast_enabled("cuda"):
             amp_dtype = torch.get_autocast_dtype("cuda")
             x_proj_weight = x_proj_weight.to(amp_dtype)
             delta_proj_weight = delta_proj_weight.to(amp_dtype)
-        x = xz[:, 0].reshape(batch, G * Dm, L)            # views: batch stride 2*G*D*l, unit l stride
+        if xz.stride() != (L, G * Dm * batch * L, Dm * batch * L, batch * L, 1):
+            xz = xz.permute(1, 2, 3, 0, 4).contiguous().permute(3, 0, 1, 2, 4)
+        x = xz[:, 0].reshape(batch, G * Dm, L)            # views with strides (l, batch*l, 1)
         z = xz[:, 1].reshape(batch, G * Dm, L)
         conv1d_bias = conv1d_bias.contiguous() if conv1d_bias is not None else None
-        conv1d_out = causal_conv1d_cuda.causal_conv1d_fwd(x, conv1d_weight, conv1d_bias, True)
-        x_dbl, delta = MambaInnerGroupedFnNoOutProj._project(conv1d_out, x_proj_weight, delta_proj_weight, batch, G)
-        x_dbl4 = x_dbl.view(batch, G, -1, L)
-        B, C = x_dbl4[:, :, R:R + N], x_dbl4[:, :, R + N:]
+        conv1d_out = _channel_major(causal_conv1d_cuda.causal_conv1d_fwd(x, conv1d_weight, conv1d_bias, True))
+        cm = MambaInnerGroupedFnNoOutProj._cm
+        x_dbl = torch.bmm(x_proj_weight, cm(conv1d_out, G))                       # (G, R + 2N, batch*l)
+        delta = torch.bmm(delta_proj_weight, x_dbl[:, :R]).view(G * Dm, batch, L).permute(1, 0, 2)
+        x_dbl4 = x_dbl.view(G, -1, batch, L)
+        B, C = x_dbl4[:, R:R + N].permute(2, 0, 1, 3), x_dbl4[:, R + N:].permute(2, 0, 1, 3)   # (batch, G, N, l) views
         out, scan_intermediates, out_z = selective_scan_cuda.fwd(
             conv1d_out, delta, A, B, C, D.contiguous(), z, delta_bias, delta_softplus)
         ctx.delta_softplus = delta_softplus
         ctx.save_for_backward(xz, conv1d_weight, conv1d_bias, x_dbl, x_proj_weight, delta_proj_weight,
                               A, D, delta_bias, scan_intermediates, out)
         return out_z
-
-    @staticmethod
-    def _project(conv1d_out, x_proj_weight, delta_proj_weight, batch, G):
-        """x_dbl^T (batch*G, R+2N, l) and delta (batch, G*D, l) from conv1d_out (batch, G*D, l)."""
-        _, GD, L = conv1d_out.shape
-        Dm = GD // G
-        E, R = x_proj_weight.shape[1], delta_proj_weight.shape[2]
-        wx = x_proj_weight.unsqueeze(0).expand(batch, G, E, Dm).reshape(batch * G, E, Dm)
-        x_dbl = torch.bmm(wx, conv1d_out.view(batch * G, Dm, L))
-        wdt = delta_proj_weight.unsqueeze(0).expand(batch, G, Dm, R).reshape(batch * G, Dm, R)
-        delta = torch.bmm(wdt, x_dbl[:, :R]).view(batch, GD, L)
-        return x_dbl, delta
 
     @staticmethod
     @custom_bwd(device_type="cuda")
@@ -246,34 +258,34 @@ class MambaInnerGroupedFnNoOutProj(torch.autograd.Function):
         batch, _, G, Dm, L = xz.shape
         E, R = x_proj_weight.shape[1], delta_proj_weight.shape[2]
         N = A.shape[-1]
+        cm = MambaInnerGroupedFnNoOutProj._cm
         x = xz[:, 0].reshape(batch, G * Dm, L)
         z = xz[:, 1].reshape(batch, G * Dm, L)
         dout = _unit_l(dout)
-        conv1d_out = causal_conv1d_cuda.causal_conv1d_fwd(x, conv1d_weight, conv1d_bias, True)
-        wx = x_proj_weight.unsqueeze(0).expand(batch, G, E, Dm).reshape(batch * G, E, Dm)
-        wdt = delta_proj_weight.unsqueeze(0).expand(batch, G, Dm, R).reshape(batch * G, Dm, R)
-        delta = torch.bmm(wdt, x_dbl[:, :R]).view(batch, G * Dm, L)
-        x_dbl4 = x_dbl.view(batch, G, E, L)
-        B, C = x_dbl4[:, :, R:R + N], x_dbl4[:, :, R + N:]
-        dxz = torch.empty_like(xz)
+        conv1d_out = _channel_major(causal_conv1d_cuda.causal_conv1d_fwd(x, conv1d_weight, conv1d_bias, True))
+        conv_g = cm(conv1d_out, G)                                                # (G, D, batch*l)
+        delta = torch.bmm(delta_proj_weight, x_dbl[:, :R]).view(G * Dm, batch, L).permute(1, 0, 2)
+        x_dbl4 = x_dbl.view(G, E, batch, L)
+        B, C = x_dbl4[:, R:R + N].permute(2, 0, 1, 3), x_dbl4[:, R + N:].permute(2, 0, 1, 3)
+        dxz = torch.empty_like(xz)                                                # keeps xz's channel-major strides
         dx = dxz[:, 0].reshape(batch, G * Dm, L)
         dz = dxz[:, 1].reshape(batch, G * Dm, L)
         dconv1d_out, ddelta, dA, dB, dC, dD, ddelta_bias, dz = selective_scan_cuda.bwd(
             conv1d_out, delta, A, B, C, D, z, delta_bias, dout, scan_intermediates, out, dz,
             ctx.delta_softplus, False)
-        ddelta_b = ddelta.view(batch * G, Dm, L)
-        dx_dbl = torch.empty_like(x_dbl)                                   # (batch*G, E, l)
-        dx_dbl4 = dx_dbl.view(batch, G, E, L)
-        dx_dbl4[:, :, R:R + N] = dB
-        dx_dbl4[:, :, R + N:] = dC
-        dx_dbl[:, :R] = torch.bmm(wdt.transpose(1, 2), ddelta_b)
-        # weight gradients: per (batch, direction) GEMM over l, then the sum over the batch in fp32
-        ddelta_proj_weight = torch.bmm(ddelta_b, x_dbl[:, :R].transpose(1, 2)).view(batch, G, Dm, R).float().sum(0)
-        conv_b = conv1d_out.view(batch * G, Dm, L)
-        dx_proj_weight = torch.bmm(dx_dbl, conv_b.transpose(1, 2)).view(batch, G, E, Dm).float().sum(0)
-        dconv1d_out = torch.baddbmm(dconv1d_out.view(batch * G, Dm, L), wx.transpose(1, 2), dx_dbl)
+        ddelta_g = cm(_channel_major(ddelta), G)                                  # (G, D, batch*l)
+        dx_dbl = torch.empty_like(x_dbl)                                          # (G, E, batch*l)
+        dx_dbl4 = dx_dbl.view(G, E, batch, L)
+        dx_dbl4[:, R:R + N] = dB.permute(1, 2, 0, 3)
+        dx_dbl4[:, R + N:] = dC.permute(1, 2, 0, 3)
+        dx_dbl[:, :R] = torch.bmm(delta_proj_weight.transpose(1, 2), ddelta_g)
+        # weight gradients: one GEMM per direction over all clips and tokens (fp32 accumulation inside the GEMM)
+        ddelta_proj_weight = torch.bmm(ddelta_g, x_dbl[:, :R].transpose(1, 2))    # (G, D, R)
+        dx_proj_weight = torch.bmm(dx_dbl, conv_g.transpose(1, 2))                # (G, E, D)
+        dconv_g = torch.baddbmm(cm(_channel_major(dconv1d_out), G), x_proj_weight.transpose(1, 2), dx_dbl)
+        dconv = dconv_g.view(G * Dm, batch, L).permute(1, 0, 2)
         dx, dconv1d_weight, dconv1d_bias = causal_conv1d_cuda.causal_conv1d_bwd(
-            x, conv1d_weight, conv1d_bias, dconv1d_out.view(batch, G * Dm, L), dx, True)
+            x, conv1d_weight, conv1d_bias, dconv, dx, True)
         return (dxz, dconv1d_weight, dconv1d_bias if conv1d_bias is not None else None, dx_proj_weight,
                 ddelta_proj_weight, dA, dD, ddelta_bias, None)
 
