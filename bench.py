@@ -137,7 +137,9 @@ def pmc_traffic(entry_point):
     this very command (tools/pmc_bench_traffic.py; bench.py cannot run the profiler on itself): the newest committed
     profiles/r*_bench_pmc_traffic.json, or None."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc_traffic.json")))
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc_traffic.json")),
+                   key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])     # r01_v10 after r01_v9
     if not files:
         return None, None
     try:
