@@ -601,19 +601,28 @@ def test_scan_random_cases_match_oracle(cuda, ops):
 
 def test_conv_random_cases_match_oracle(cuda, ops):
     """Random conv1d problems (width, bias, activation, row length incl. lengths shorter than the filter, dtype,
-    strided rows) against the C oracle, forward and backward."""
+    contiguous / strided / channel-last rows) against the C oracle, forward and backward."""
     hyp, st = _hyp()
     _, cc = ops
 
-    @hyp.settings(max_examples=60, deadline=None, derandomize=True, suppress_health_check=list(hyp.HealthCheck))
+    @hyp.settings(max_examples=120, deadline=None, derandomize=True, suppress_health_check=list(hyp.HealthCheck))
     @hyp.given(batch=st.integers(1, 3), dim=st.sampled_from([1, 2, 7, 64, 130]), width=st.integers(2, 4),
                L=st.one_of(st.integers(1, 20), st.sampled_from([255, 256, 257, 1023, 2056])),
                dtype=st.sampled_from([torch.float32, torch.bfloat16, torch.float16]), has_bias=st.booleans(),
-               silu=st.booleans(), strided=st.booleans(), seed=st.integers(0, 2 ** 16))
-    def run(batch, dim, width, L, dtype, has_bias, silu, strided, seed):
+               silu=st.booleans(), layout=st.sampled_from(["contiguous", "strided", "channel_last", "channel_last_wide"]),
+               seed=st.integers(0, 2 ** 16))
+    def run(batch, dim, width, L, dtype, has_bias, silu, layout, seed):
         g = torch.Generator().manual_seed(seed)
-        mk = lambda: (torch.randn(dim, batch, L, generator=g).to(dtype).to(cuda).transpose(0, 1) if strided
-                      else torch.randn(batch, dim, L, generator=g).to(dtype).to(cuda))
+
+        def mk():
+            if layout == "strided":                   # Vivim's (L, B*L, 1)
+                return torch.randn(dim, batch, L, generator=g).to(dtype).to(cuda).transpose(0, 1)
+            if layout == "channel_last":              # unit stride along channels (csrc/conv1d_cl.hip)
+                return torch.randn(batch, L, dim, generator=g).to(dtype).to(cuda).transpose(1, 2)
+            if layout == "channel_last_wide":         # ... as a channel slice of a wider tensor: unaligned rows
+                return torch.randn(batch, L, dim + 5, generator=g).to(dtype).to(cuda)[:, :, 3:3 + dim].transpose(1, 2)
+            return torch.randn(batch, dim, L, generator=g).to(dtype).to(cuda)
+
         x, dout = mk(), mk()
         w = torch.randn(dim, width, generator=g).to(cuda)
         b = torch.randn(dim, generator=g).to(cuda) if has_bias else None
