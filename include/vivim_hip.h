@@ -29,7 +29,7 @@
  * Differences from the reference structs, on purpose: strides are int64 (a 288 GB HBM3E part holds
  * tensors past 2^32 elements; the reference uses uint32, selective_scan.h:27); the input dtype is an
  * explicit enum instead of a C++ template dispatch; `x` (scan checkpoints) has OUR chunk length,
- * vivim_scan_chunk_len(), instead of the reference's fixed 2048 (selective_scan.cpp:307).
+ * vivim_scan_ckpt_len(), instead of the reference's fixed 2048 (selective_scan.cpp:307).
  */
 #ifndef VIVIM_HIP_H
 #define VIVIM_HIP_H
@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define VIVIM_ABI_VERSION 5
+#define VIVIM_ABI_VERSION 6
 
 typedef enum { VIVIM_F32 = 0, VIVIM_F16 = 1, VIVIM_BF16 = 2 } vivim_dtype_t;
 
@@ -77,7 +77,7 @@ typedef struct {
     void *out;                  /* (batch, dim, seqlen) itype: y + D*u, before gating */
     void *out_z;                /* out * silu(z); required iff z != NULL */
     void *x;                    /* (batch, dim, n_chunks, dstate) f32 contiguous: state after each chunk of
-                                   vivim_scan_chunk_len() tokens; x[:, :, -1, :] is the final state
+                                   vivim_scan_ckpt_len() tokens; x[:, :, -1, :] is the final state
                                    (the reference's x[:, :, -1, 1::2], selective_scan_interface.py:40) */
     void *workspace;            /* forward only: device scratch of >= vivim_scan_fwd_workspace_bytes() bytes or NULL
                                    (NULL selects a kernel that needs none); ignored inside vivim_ssm_bwd_params.f */
@@ -236,7 +236,12 @@ const char *vivim_last_error(void);
  * 8 state_update; 0 for anything else. */
 size_t vivim_sizeof(int which);
 
-/* Tokens per checkpoint row of `x` for an input dtype; n_chunks = ceil(seqlen / chunk_len). */
+/* Tokens per checkpoint row of `x`: n_chunks = ceil(seqlen / vivim_scan_ckpt_len(f)).  Depends on the sizes and flags in
+ * `f` (not on its pointers) and on the forward tuning value: 16 * (dstate / 16) for the shapes the lanes = states
+ * backward takes (variable B / C, dstate 16 / 32 / 64), vivim_scan_chunk_len() otherwise.  The forward call, the
+ * backward call and the allocation of `x` must see the same value. */
+int vivim_scan_ckpt_len(const vivim_ssm_fwd_params *f);
+/* The checkpoint length of the shapes the call above does not special-case. */
 int vivim_scan_chunk_len(int itype);
 
 /* Scratch the backward wants for splitting the token axis over workgroups (carries of the reverse
@@ -247,8 +252,9 @@ size_t vivim_scan_bwd_workspace_bytes(const vivim_ssm_fwd_params *f);
 size_t vivim_scan_fwd_workspace_bytes(const vivim_ssm_fwd_params *f);
 
 /* Kernel-selection override for tuning and tests: which = 0 forward scan (0 automatic, 1 n-split K=8, 2 n-split K=4,
- * 3 generic, 5 lanes=channels), which = 1 backward scan (0 automatic, 1 / 2 fast kernel with 8 / 4 waves per workgroup,
- * 3 generic).  Returns the previous value, -1 on a bad argument.  Initial values come from VIVIM_FWD_VARIANT / VIVIM_BWD_VARIANT.  The forward workspace size depends on
+ * 3 generic, 5 lanes=channels, 6 lanes=states), which = 1 backward scan (0 automatic, 1 / 2 lanes=tokens kernel with
+ * 8 / 4 waves per workgroup, 3 generic, 4 lanes=states).  Forward values 1-3 also select the long checkpoint rows
+ * (vivim_scan_ckpt_len), which the lanes=states backward cannot use.  Returns the previous value, -1 on a bad argument.  Initial values come from VIVIM_FWD_VARIANT / VIVIM_BWD_VARIANT.  The forward workspace size depends on
  * the forward setting: query it after changing it. */
 int vivim_set_tuning(int which, int value);
 

@@ -359,8 +359,8 @@ def test_scan_optional_arguments(has_z, has_D, has_bias, softplus, cuda, ops):
 
 # Every forward / backward kernel family must agree with the oracle, not only the one the dispatcher prefers:
 # vivim_set_tuning (include/vivim_hip.h) pins the family for the duration of a test.
-FWD_VARIANTS = {"auto": 0, "nsplit_k8": 1, "nsplit_k4": 2, "generic": 3, "channels": 5}
-BWD_VARIANTS = {"auto": 0, "fast_w8": 1, "fast_w4": 2, "generic": 3}
+FWD_VARIANTS = {"auto": 0, "nsplit_k8": 1, "nsplit_k4": 2, "generic": 3, "channels": 5, "states": 6}
+BWD_VARIANTS = {"auto": 0, "fast_w8": 1, "fast_w4": 2, "generic": 3, "states": 4}
 
 
 @pytest.fixture
@@ -384,15 +384,17 @@ def tuning():
                                                 (torch.float16, 2, 256, 320, 2), (torch.bfloat16, 1, 192, 8, 1)])
 def test_scan_kernel_families(fwd, bwd, dtype, batch, dim, L, G, cuda, ops, tuning):
     """Vivim-shaped problems (dstate 16, whole 64-channel blocks, aligned rows) are eligible for every family:
-    n-split K=8 / K=4, lanes=channels (token-axis segments + carry kernel), generic; fast (8 or 4 waves per workgroup) /
-    generic backward."""
+    n-split K=8 / K=4, lanes=channels (token-axis segments + carry kernel), lanes=states, generic; lanes=tokens (8 or 4
+    waves per workgroup) / lanes=states / generic backward.  The forward family also decides the checkpoint spacing of
+    `x` (vivim_scan_ckpt_len): the lanes=tokens backward needs the long rows of forward 1-3 and the lanes=states one the
+    short rows of the others; a pinned backward that cannot read the rows it gets falls back to the generic kernel."""
     ss, _ = ops
     tuning(FWD_VARIANTS[fwd], BWD_VARIANTS[bwd])
     gen = torch.Generator().manual_seed(dim + L)
     _check_scan(_rand_scan(gen, batch, dim, 16, L, G, dtype, cuda, init="module"), ss)
 
 
-@pytest.mark.parametrize("fwd", ["nsplit_k8", "channels"])
+@pytest.mark.parametrize("fwd", ["nsplit_k8", "channels", "states"])
 def test_scan_kernel_families_strided_long(fwd, cuda, ops, tuning):
     """(L, B*L, 1)-strided rows, many token-axis segments (L = 20480: S > 1 in the channels kernels)."""
     ss, _ = ops

@@ -104,7 +104,7 @@ class StateUpdateParams(ctypes.Structure):
                 + [(n, vp) for n in ("state", "x", "dt", "A", "B", "C", "D", "z", "dt_bias", "out")])
 
 
-EXPORTS = ("vivim_abi_version", "vivim_last_error", "vivim_scan_chunk_len", "vivim_sizeof",
+EXPORTS = ("vivim_abi_version", "vivim_last_error", "vivim_scan_chunk_len", "vivim_scan_ckpt_len", "vivim_sizeof",
            "vivim_scan_bwd_workspace_bytes", "vivim_scan_fwd_workspace_bytes", "vivim_set_tuning",
            "vivim_selective_scan_fwd", "vivim_selective_scan_bwd",
            "vivim_causal_conv1d_fwd", "vivim_causal_conv1d_bwd", "vivim_dwconv_fwd", "vivim_dwconv_wgrad",
@@ -135,6 +135,8 @@ def lib():
         L.vivim_sizeof.argtypes = [ctypes.c_int]
         L.vivim_set_tuning.restype = ctypes.c_int
         L.vivim_set_tuning.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.vivim_scan_ckpt_len.restype = ctypes.c_int
+        L.vivim_scan_ckpt_len.argtypes = [ctypes.POINTER(SsmFwdParams)]
         for fn in (L.vivim_scan_bwd_workspace_bytes, L.vivim_scan_fwd_workspace_bytes):
             fn.restype = ctypes.c_size_t
             fn.argtypes = [ctypes.POINTER(SsmFwdParams)]
@@ -147,7 +149,7 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = [ctypes.POINTER(st), vp]
             fn.restype = ctypes.c_int
-        if L.vivim_abi_version() != 5:
+        if L.vivim_abi_version() != 6:
             raise ImportError("libvivim_hip.so ABI version mismatch")
         for which, st in enumerate((SsmFwdParams, SsmBwdParams, ConvFwdParams, ConvBwdParams, DwConvParams,
                                     DwConvWgradParams, DirParams, ConvUpdateParams, StateUpdateParams)):

@@ -19,6 +19,7 @@ void conv_update_launch(const vivim_conv_update_params&, hipStream_t);          
 void state_update_launch(const vivim_state_update_params&, hipStream_t);
 bool ssm_bwd_dispatch(const vivim_ssm_bwd_params&, hipStream_t);
 int scan_chunk_len(int itype);
+int scan_ckpt_len(const vivim_ssm_fwd_params&);
 size_t scan_bwd_workspace_bytes(const vivim_ssm_fwd_params&);
 size_t scan_fwd_workspace_bytes(const vivim_ssm_fwd_params&);
 }  // namespace vivim
@@ -53,7 +54,7 @@ static int check_ssm_fwd(const vivim_ssm_fwd_params* p, bool is_bwd) {
     VCHECK(p->dstate <= 256);                       // selective_scan.cpp:262
     VCHECK(p->dim % p->n_groups == 0);
     VCHECK(p->u && p->delta && p->A && p->B && p->C);
-    VCHECK(p->x != nullptr || (is_bwd && p->seqlen <= vivim::scan_chunk_len(p->itype)));
+    VCHECK(p->x != nullptr || (is_bwd && p->seqlen <= vivim::scan_ckpt_len(*p)));
     if (!is_bwd) VCHECK(p->out != nullptr);
     if (p->z) {
         if (!is_bwd) VCHECK(p->out_z != nullptr);
@@ -93,6 +94,7 @@ int vivim_set_tuning(int which, int value) {
 int vivim_abi_version(void) { return VIVIM_ABI_VERSION; }
 const char* vivim_last_error(void) { return g_err; }
 int vivim_scan_chunk_len(int itype) { return vivim::scan_chunk_len(itype); }
+int vivim_scan_ckpt_len(const vivim_ssm_fwd_params* f) { return f ? vivim::scan_ckpt_len(*f) : 0; }
 size_t vivim_scan_bwd_workspace_bytes(const vivim_ssm_fwd_params* f) {
     return f ? vivim::scan_bwd_workspace_bytes(*f) : 0;
 }

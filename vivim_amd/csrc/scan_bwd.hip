@@ -19,10 +19,16 @@
 
 namespace vivim {
 
+int scan_ckpt_len(const vivim_ssm_fwd_params&);                          // scan_fwd.hip
+bool ls_shape_ok(const vivim_ssm_fwd_params&);                           // scan_ls.hip
+int ls_ckpt_len(const vivim_ssm_fwd_params&);
+bool try_ls_bwd(const vivim_ssm_bwd_params&, hipStream_t);
+size_t ls_bwd_workspace_bytes(const vivim_ssm_fwd_params&);
+
 constexpr int kBwdWaves = 4;
 
 template <typename T, int K, int R, bool HAS_Z, bool VAR_BC>
-__global__ void __launch_bounds__(kBwdWaves * kWave) ssm_bwd_generic_kernel(const vivim_ssm_bwd_params p) {
+__global__ void __launch_bounds__(kBwdWaves * kWave) ssm_bwd_generic_kernel(const vivim_ssm_bwd_params p, const int ck) {
     constexpr int TILE = kWave * K;
     const vivim_ssm_fwd_params& f = p.f;
     const int lane = threadIdx.x & 63;
@@ -66,6 +72,7 @@ __global__ void __launch_bounds__(kBwdWaves * kWave) ssm_bwd_generic_kernel(cons
     float* __restrict__ dCg = static_cast<float*>(p.dC);
     const float* __restrict__ xck = static_cast<const float*>(f.x);
     const int nsteps = (L + TILE - 1) / TILE;
+    const int nck = (L + ck - 1) / ck;                 // checkpoint rows of x: one per ck tokens (ck divides TILE)
 
     for (int step = nsteps - 1; step >= 0; --step) {
         const int t0 = step * TILE + lane * K;
@@ -139,7 +146,7 @@ __global__ void __launch_bounds__(kBwdWaves * kWave) ssm_bwd_generic_kernel(cons
                 float Pe = __shfl_up(P, 1, kWave), He = __shfl_up(H, 1, kWave);
                 if (lane == 0) { Pe = 1.0f; He = 0.0f; }
                 const float hstep = step > 0
-                    ? xck[(((int64_t)b * f.dim + d[r]) * nsteps + (step - 1)) * N + n] : 0.0f;
+                    ? xck[(((int64_t)b * f.dim + d[r]) * nck + (step * (TILE / ck) - 1)) * N + n] : 0.0f;
                 float hc = fmaf(Pe, hstep, He);
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
@@ -852,7 +859,19 @@ static BwdPlan bwd_plan(const vivim_ssm_fwd_params& f) {
     return q;
 }
 
+// The lanes = states family (scan_ls.hip) takes every shape whose checkpoints were written for it (scan_ckpt_len), unless
+// the tuning selector pins one of the kernels of this file (1 / 2: fast kernel with 8 / 4 waves, 3: generic; 4 pins it).
+static bool bwd_takes_ls(const vivim_ssm_fwd_params& f) {
+    const int tv = tuning_bwd_variant();
+    return ls_shape_ok(f) && scan_ckpt_len(f) == ls_ckpt_len(f) && (tv == 0 || tv == 4);
+}
+
+static size_t fast_bwd_workspace_bytes(const vivim_ssm_fwd_params& f);
 size_t scan_bwd_workspace_bytes(const vivim_ssm_fwd_params& f) {
+    if (bwd_takes_ls(f)) return ls_bwd_workspace_bytes(f);
+    return fast_bwd_workspace_bytes(f);
+}
+static size_t fast_bwd_workspace_bytes(const vivim_ssm_fwd_params& f) {
     if (!f.is_variable_B || !f.is_variable_C || f.dstate > 64) return 0;
     const BwdPlan q = bwd_plan(f);
     if (q.S <= 1) return 0;
@@ -866,7 +885,7 @@ static void launch_bwd_fast(const vivim_ssm_bwd_params& p, const BwdPlan& plan, 
     const int ppg = (cpg + kBwR - 1) / kBwR;
     const int bpg = (ppg + W - 1) / W;
     BwdSeg sg = {1, (f.seqlen + kWave * K - 1) / (kWave * K), nullptr, nullptr, nullptr};
-    const size_t need = scan_bwd_workspace_bytes(f);
+    const size_t need = fast_bwd_workspace_bytes(f);
     if (need && p.workspace && (size_t)p.workspace_bytes >= need) {
         sg.S = plan.S;
         sg.seg_steps = plan.seg_steps;
@@ -917,6 +936,7 @@ static bool try_bwd_fast_k(const vivim_ssm_bwd_params& p, hipStream_t stream) {
     const vivim_ssm_fwd_params& f = p.f;
     if (!f.is_variable_B || !f.is_variable_C || f.dstate > 64 || f.x == nullptr) return false;
     if (tuning_bwd_variant() == 3) return false;
+    if (scan_ckpt_len(f) != kChunk) return false;          // this family reads one checkpoint row per kChunk tokens
     // unconditional K-element vectors: rows aligned to the vector size, seqlen a whole number of lanes
     const int64_t vb = K * (int64_t)sizeof(T) >= 16 ? 16 : K * (int64_t)sizeof(T);
     const int64_t epv = vb / (int64_t)sizeof(T);
@@ -960,15 +980,16 @@ static void launch_bwd(const vivim_ssm_bwd_params& p, hipStream_t stream) {
     const size_t smem = (size_t)kBwdWaves * 3 * R * f.dstate * sizeof(float);
     const bool var = f.is_variable_B;
     if (f.z) {
-        if (var) hipLaunchKernelGGL((ssm_bwd_generic_kernel<T, K, R, true, true>), grid, dim3(kBwdWaves * kWave), smem, stream, p);
-        else     hipLaunchKernelGGL((ssm_bwd_generic_kernel<T, K, R, true, false>), grid, dim3(kBwdWaves * kWave), smem, stream, p);
+        if (var) hipLaunchKernelGGL((ssm_bwd_generic_kernel<T, K, R, true, true>), grid, dim3(kBwdWaves * kWave), smem, stream, p, scan_ckpt_len(f));
+        else     hipLaunchKernelGGL((ssm_bwd_generic_kernel<T, K, R, true, false>), grid, dim3(kBwdWaves * kWave), smem, stream, p, scan_ckpt_len(f));
     } else {
-        if (var) hipLaunchKernelGGL((ssm_bwd_generic_kernel<T, K, R, false, true>), grid, dim3(kBwdWaves * kWave), smem, stream, p);
-        else     hipLaunchKernelGGL((ssm_bwd_generic_kernel<T, K, R, false, false>), grid, dim3(kBwdWaves * kWave), smem, stream, p);
+        if (var) hipLaunchKernelGGL((ssm_bwd_generic_kernel<T, K, R, false, true>), grid, dim3(kBwdWaves * kWave), smem, stream, p, scan_ckpt_len(f));
+        else     hipLaunchKernelGGL((ssm_bwd_generic_kernel<T, K, R, false, false>), grid, dim3(kBwdWaves * kWave), smem, stream, p, scan_ckpt_len(f));
     }
 }
 
 bool ssm_bwd_dispatch(const vivim_ssm_bwd_params& p, hipStream_t s) {
+    if (bwd_takes_ls(p.f) && try_ls_bwd(p, s)) return true;
     switch (p.f.itype) {
         case VIVIM_F32: if (!try_bwd_fast<float>(p, s)) launch_bwd<float, 4, 2>(p, s); return true;
         case VIVIM_F16: if (!try_bwd_fast<f16_t>(p, s)) launch_bwd<f16_t, 4, 2>(p, s); return true;

@@ -408,7 +408,7 @@ static bool try_fwd_nsplit(const vivim_ssm_fwd_params& p, hipStream_t stream) {
     const int64_t nwg = (int64_t)((p.dim / p.n_groups + kNsR - 1) / kNsR) * p.n_groups * p.batch;
     // Measured at the grouped v3 shapes (dim = 3 * d_inner, tools/kbench.py --groups 3): K=8 wins for long rows (L 20480:
     // 365 vs 503 us, L 5120: 160 vs 188 us), K=4 for short ones (L 1280: 112 vs 130 us, L 320: 68 vs 87 us).
-    int variant = (forced && forced != 5) ? forced : ((nwg >= 512 && p.seqlen < 4096) ? 2 : 1);
+    int variant = (forced && forced < 5) ? forced : ((nwg >= 512 && p.seqlen < 4096) ? 2 : 1);
     switch (variant) {
         case 2:  launch_fwd_nsplit<T, 4, 8, 2>(p, stream); break;     // K=4
         case 3:  return false;                                         // generic kernel (tuning only)
@@ -433,15 +433,37 @@ static void launch_fwd(const vivim_ssm_fwd_params& p, hipStream_t stream) {
     }
 }
 
-// tokens per checkpoint row of x: the generic kernel (K=4) writes one row per 256-token step, the n-split
-// kernel (K=8, 512-token steps) two.
+// Tokens per checkpoint row of x.  The lanes = states backward (scan_ls.hip) rebuilds the forward states of a 16-token tile
+// from a checkpoint, so every shape it takes gets one row per 16 * (dstate / 16) tokens, written by the lanes = channels
+// and lanes = states forward kernels; the n-split / generic kernels write one row per kChunk tokens (two per 512-token
+// n-split step) and are only reached for other shapes or when the tuning selector pins them.  A pure function of the
+// shape and of the forward tuning value: forward and backward calls must see the same one.
+bool ls_shape_ok(const vivim_ssm_fwd_params&);                           // scan_ls.hip
+int ls_ckpt_len(const vivim_ssm_fwd_params&);
+bool try_ls_fwd(const vivim_ssm_fwd_params&, hipStream_t);
+size_t ls_fwd_workspace_bytes(const vivim_ssm_fwd_params&);
+bool try_fwd_chan(const vivim_ssm_fwd_params& p, hipStream_t stream);   // scan_fwd_chan.hip
+size_t fwd_chan_workspace_bytes(const vivim_ssm_fwd_params&);
+
+static bool fwd_tuning_allows_ls() { const int t = tuning_fwd_variant(); return t == 0 || t == 5 || t == 6; }
+int scan_ckpt_len(const vivim_ssm_fwd_params& f) {
+    return (ls_shape_ok(f) && fwd_tuning_allows_ls()) ? ls_ckpt_len(f) : kChunk;
+}
 int scan_chunk_len(int) { return kChunk; }
 static_assert(kWave * 4 == kChunk, "generic kernel step must equal the checkpoint chunk");
 
-bool try_fwd_chan(const vivim_ssm_fwd_params& p, hipStream_t stream);   // scan_fwd_chan.hip
+size_t scan_fwd_workspace_bytes(const vivim_ssm_fwd_params& f) {
+    if (!(ls_shape_ok(f) && fwd_tuning_allows_ls())) return 0;
+    // either family may run (the lanes = channels one also wants aligned rows, known only at launch): ask for the larger
+    const size_t a = fwd_chan_workspace_bytes(f), b = ls_fwd_workspace_bytes(f);
+    return a > b ? a : b;
+}
 
 bool ssm_fwd_dispatch(const vivim_ssm_fwd_params& p, hipStream_t s) {
-    if (try_fwd_chan(p, s)) return true;               // lanes = channels: long, wide problems (or tuning 5); needs the workspace
+    if (ls_shape_ok(p) && fwd_tuning_allows_ls()) {
+        if (tuning_fwd_variant() != 6 && try_fwd_chan(p, s)) return true;   // lanes = channels: long, wide problems (or tuning 5)
+        return try_ls_fwd(p, s);                                             // lanes = states
+    }
     switch (p.itype) {
         case VIVIM_F32: if (!try_fwd_nsplit<float>(p, s)) launch_fwd<float, 4, 2>(p, s); return true;
         case VIVIM_F16: if (!try_fwd_nsplit<f16_t>(p, s)) launch_fwd<f16_t, 4, 2>(p, s); return true;

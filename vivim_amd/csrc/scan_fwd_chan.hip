@@ -27,6 +27,7 @@ namespace vivim {
 
 constexpr int kChN = 16;           // states (compile time: they live in registers)
 constexpr int kChWaves = 2;        // independent waves per workgroup
+constexpr int kChCk = 16;          // tokens per checkpoint row of x: what the lanes = states backward wants (scan_ls.hip)
 constexpr int kChTT = 16;          // tokens per tile (16-bit: 32-byte row pieces, 9 KB of LDS per wave; fp32: 64-byte, 15 KB)
 
 struct FwdSeg {
@@ -176,7 +177,7 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
     constexpr int NIO = kWave / RPI;                  // instructions per tile and stream
     constexpr int ROWB = RB + 16;                     // padded LDS row, bytes (conflict-free 8/16-byte own-row access)
     constexpr int NARR = PASS == 2 && HAS_Z ? 3 : 2;  // resident tiles: u, delta (, z)
-    constexpr int TB = 4;                             // tokens per compute block (L % TB == 0, kChunk % TB == 0)
+    constexpr int TB = 4;                             // tokens per compute block (L % TB == 0, kChCk % TB == 0)
     typedef uint32_t __attribute__((ext_vector_type(4))) v4;
     typedef typename Pack<T, TB * (int)sizeof(T)>::type vblk;
     __shared__ __attribute__((aligned(16))) unsigned char lds[kChWaves * NARR * kWave * ROWB];
@@ -212,7 +213,7 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
     const float bias = p.delta_bias ? static_cast<const float*>(p.delta_bias)[d] : 0.0f;
     const bool sp_on = p.delta_softplus;
     const float* __restrict__ bc = sg.BC + (int64_t)(b * p.n_groups + g) * (sg.Lpad + 1) * 32;
-    const int nck = (L + kChunk - 1) / kChunk;
+    const int nck = (L + kChCk - 1) / kChCk;
     float* __restrict__ xlane = static_cast<float*>(p.x) + ((int64_t)b * p.dim + d) * nck * N;   // per-lane (VGPRs)
 
     // cooperative tile I/O: instruction i moves rows i*16 + lane/4, 16-byte column lane%4
@@ -310,10 +311,10 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
                 if (PASS == 2) yo[k + 1] = y2.x + y2.y;
             }
             if (PASS == 2) {
-                // state after every kChunk tokens and after the last one: always the last token of a block
+                // state after every kChCk tokens and after the last one: always the last token of a block
                 const int tl = tb + TB - 1;
-                if (((tl + 1) & (kChunk - 1)) == 0 || tl == L - 1) {
-                    float* xr = xlane + (tl / kChunk) * N;
+                if (((tl + 1) & (kChCk - 1)) == 0 || tl == L - 1) {
+                    float* xr = xlane + (tl / kChCk) * N;
 #pragma unroll
                     for (int n = 0; n < N; ++n) xr[n] = (n & 1) ? hp[n / 2].y : hp[n / 2].x;
                 }
@@ -466,7 +467,7 @@ static size_t fwd_chan_layout(const vivim_ssm_fwd_params& f, int tt, int& S, int
     return (bc_floats + h_floats) * sizeof(float);
 }
 
-size_t scan_fwd_workspace_bytes(const vivim_ssm_fwd_params& f) {
+size_t fwd_chan_workspace_bytes(const vivim_ssm_fwd_params& f) {
     if (!fwd_chan_eligible(f, true)) return 0;
     int S, seg_tiles, Lpad;
     size_t bc;

@@ -1,0 +1,1142 @@
+// scan_ls.hip -- selective SSM scan, forward and backward, "lanes = states" kernels (gfx950, wave64).
+//
+// Same math as the reference kernels (selective_scan_fwd_kernel.cuh:67-303, selective_scan_bwd_kernel.cuh:75-489,
+// real A, variable B / C); the mapping is built on what tools/valu_lab*.hip measured on MI355X:
+// a VGPR-only v_fma / v_mul / v_add issues at 32 lanes per clock, a v_exp_f32 costs ~3.5 of them, and every
+// cross-lane form (DPP, v_readlane, v_permlane*_swap) and every SGPR-operand form issues at half rate or worse.
+// So the recurrences must be serial IN a lane, and the operands a lane cannot own must cost one DPP each, no more.
+//
+//   * a 16-lane ROW is one (batch, channel) stream; the lane index inside the row is the STATE n, so the 16 (32, 64)
+//     recurrences h_n <- a_n h_n + b_n of a channel run side by side, one per lane, serial along the tokens: no
+//     scan, no carry between lanes, no barrier.  dstate 32 / 64 take 2 / 4 rows per channel.
+//   * a TILE is 16 tokens.  What is shared by the states of a channel -- delta_t, delta_t u_t, dy_t -- is computed once,
+//     by the lane that holds token t of the tile (lane r holds token bitrev4(r), see below), and enters the
+//     recurrence of all 16 lanes as a DPP row broadcast operand (v_mul_f32_dpp ... row_newbcast).  What differs per
+//     state -- B_{n,t}, C_{n,t}, A_n -- is the lane's own: it loads 16 consecutive tokens of ITS row of B and C.
+//   * sums over the states (y_t; S1_t = sum_n g B, S2_t = sum_n A g a h) are transposed 16 x 16 reductions: pairs of
+//     token-vectors are merged with two masked DPP adds per level (bank_mask for the 8- and 4-lane levels, a select
+//     pair for the 2- and 1-lane ones), 30 DPP adds for 16 tokens, and leave the total of token t in the lane that owns
+//     token t -- the bit-reversed token order is what makes the merge tree consume tokens in loop order.
+//   * backward: the forward states of a tile are recomputed from the forward kernel's checkpoint (one row of `x`
+//     per 16 * rows tokens: 4 bytes per token and channel, written by the forward kernels of this file and by
+//     scan_fwd_chan.hip) and kept in registers (a_t, h_t: 32 VGPRs) for the reverse sweep over the same 16 tokens.
+//   * dB_{n,t} / dC_{n,t} are sums over channels: a row walks kLsCPR channels per tile and keeps the sum in
+//     registers; the rows and waves of a workgroup (16 * W channels of one B/C group) are then added through LDS in
+//     fixed order.  When the workgroup covers its whole group (Vivim stage 0: 128 channels) the result is STORED:
+//     no atomics, bit-reproducible; wider groups add one fp32 atomic per workgroup (reference: one per channel,
+//     selective_scan_bwd_kernel.cuh:312-313).
+//   * the token axis is cut into segments for parallelism (ls_segmentation); a segment's inflow (h from the left in
+//     the forward, g from the right in the backward) comes from a pre-pass (recurrence only) and a carry kernel.
+// No alignment requirement: every activation access is one element per lane.
+#include <stdlib.h>
+#include <type_traits>
+#include "common.cuh"
+
+namespace vivim {
+
+constexpr int kLsT = 16;           // tokens per tile
+constexpr int kLsCPR = 4;          // channels a row walks per tile
+
+__host__ __device__ constexpr int br4(int k) { return ((k & 1) << 3) | ((k & 2) << 1) | ((k & 4) >> 1) | ((k & 8) >> 3); }
+
+// value held by lane K of this lane's 16-lane row
+template <int K> __device__ __forceinline__ float row_bc(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + K, 0xf, 0xf, true));
+}
+// value of token K of the tile (token K lives in lane bitrev4(K) of every row)
+template <int K> __device__ __forceinline__ float tok(float v) { return row_bc<br4(K)>(v); }
+
+// acc + token_K(src) * mul as ONE instruction (v_fmac_f32 with a DPP row broadcast on src).  hipcc folds the broadcast into
+// v_mul_f32 by itself but not into v_fmac_f32 (it emits v_mov_b32_dpp + v_fmac_f32).  Written as a dependent update of
+// `acc` on purpose: a product that does not depend on the running value gets hoisted out of the 16-token recurrence by
+// the scheduler, 16 temporaries at a time.
+template <int K> __device__ __forceinline__ float tok_fma(float acc, float src, float mul) {
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(br4(K)));
+    return acc;
+}
+
+// The per-token values (delta, delta * u, dy) are read through DPP by inline asm (tok_fma), where hipcc does not see the
+// "VALU write -> DPP read needs two wait states" hazard: pass them through this once, right after they are computed --
+// from here on they are only read.  (Without it the broadcasts of the LAST channel of a tile returned stale registers.)
+__device__ __forceinline__ void ls_settle(float& a, float& b, float& c) { asm volatile("s_nop 1" : "+v"(a), "+v"(b), "+v"(c)); }
+__device__ __forceinline__ void ls_settle(float& a, float& b) { asm volatile("s_nop 1" : "+v"(a), "+v"(b)); }
+// "These sixteen registers are used HERE": placed right after the loads of a tile's B / C rows, it makes hipcc wait for them
+// before the channel loop instead of at their first use inside it (where it cannot count what else is in flight).
+__device__ __forceinline__ void ls_arrive(float (&v)[16]) {
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                      "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
+}
+
+template <int I, int N, typename F> __device__ __forceinline__ void sfor(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); sfor<I + 1, N>(f); }
+}
+template <int I, typename F> __device__ __forceinline__ void sfor_down(F&& f) {      // I-1, I-2, ..., 0
+    if constexpr (I > 0) { f(std::integral_constant<int, I - 1>{}); sfor_down<I - 1>(f); }
+}
+
+// ---- transposed 16-lane reduction: merge two vectors, each lane keeps the pair sum of ONE of them --------------------
+// level 8: lanes 0-7 of a row get X[r] + X[r+8], lanes 8-15 get Y[r-8] + Y[r].  The leading s_nop covers the DPP read
+// hazard against the (compiler-scheduled) VALU producers of X / Y.  EXEC must be all ones (it is: uniform code).
+__device__ __forceinline__ float ls_merge8(float X, float Y) {
+    float Z;
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc" : "=&v"(Z) : "v"(X), "v"(Y));
+    return Z;
+}
+// level 4: lanes with bit 2 clear get X[r] + X[r+4], lanes with bit 2 set get Y[r-4] + Y[r]
+__device__ __forceinline__ float ls_merge4(float X, float Y) {
+    float Z;
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa" : "=&v"(Z) : "v"(X), "v"(Y));
+    return Z;
+}
+// levels 2 and 1: no DPP write mask is finer than a bank of four lanes, and an EXEC mask would also invalidate the SOURCE
+// lanes of the DPP read, so each lane first selects what it keeps and what it sends (v_cndmask issues beside the
+// plain VALU work, valu_lab3: pattern CP), then one DPP add exchanges inside the quad.
+// level 2: lanes 0,1 of a quad get X[r] + X[r+2], lanes 2,3 get Y[r-2] + Y[r]
+__device__ __forceinline__ float ls_merge2(float X, float Y, bool hi) {
+    const float keep = hi ? Y : X, send = hi ? X : Y;
+    return keep + dpp_mov<0x4e>(0.0f, send);            // quad_perm:[2,3,0,1]
+}
+// level 1: even lanes get X[r] + X[r+1], odd lanes get Y[r-1] + Y[r]
+__device__ __forceinline__ float ls_merge1(float X, float Y, bool hi) {
+    const float keep = hi ? Y : X, send = hi ? X : Y;
+    return keep + dpp_mov<0xb1>(0.0f, send);            // quad_perm:[1,0,3,2]
+}
+// Incremental use: feed the 16 per-token vectors in an order that completes pairs (2j, 2j+1) -- an ascending or a
+// descending loop -- so that at most five partial vectors are live.  Result: lane r holds the total of token
+// bitrev4(r), i.e. of the token that lane owns.
+// merges for a DESCENDING token loop: call after token K has been produced
+template <int K> __device__ __forceinline__ void ls_reduce_down(float (&s)[16], float (&z)[8], float (&w)[4], float (&v)[2], float& out, int li) {
+    if constexpr ((K & 1) == 0) z[K / 2] = ls_merge8(s[K], s[K + 1]);
+    if constexpr ((K & 3) == 0) w[K / 4] = ls_merge4(z[K / 2], z[K / 2 + 1]);
+    if constexpr ((K & 7) == 0) v[K / 8] = ls_merge2(w[K / 4], w[K / 4 + 1], (li & 2) != 0);
+    if constexpr (K == 0) out = ls_merge1(v[0], v[1], (li & 1) != 0);
+}
+// merges for an ASCENDING token loop
+template <int K> __device__ __forceinline__ void ls_reduce_up(float (&s)[16], float (&z)[8], float (&w)[4], float (&v)[2], float& out, int li) {
+    if constexpr ((K & 1) == 1) z[K / 2] = ls_merge8(s[K - 1], s[K]);
+    if constexpr ((K & 3) == 3) w[K / 4] = ls_merge4(z[K / 2 - 1], z[K / 2]);
+    if constexpr ((K & 7) == 7) v[K / 8] = ls_merge2(w[K / 4 - 1], w[K / 4], (li & 2) != 0);
+    if constexpr (K == 15) out = ls_merge1(v[0], v[1], (li & 1) != 0);
+}
+
+// sum over the RPS rows of a stream (dstate 32 / 64): every row ends with the total
+template <int RPS> __device__ __forceinline__ float ls_rows_sum(float x) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    if constexpr (RPS >= 2) {
+        const u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+        x = __uint_as_float(r.x) + __uint_as_float(r.y);
+    }
+    if constexpr (RPS >= 4) {
+        const u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+        x = __uint_as_float(r.x) + __uint_as_float(r.y);
+    }
+    return x;
+}
+// sum over the 16 lanes of a row, total in every lane
+__device__ __forceinline__ float ls_row_total(float v) {
+    v += dpp_mov<0x128>(0.0f, v);       // row_ror:8
+    v += dpp_mov<0x124>(0.0f, v);       // row_ror:4
+    v += dpp_mov<0x122>(0.0f, v);       // row_ror:2
+    v += dpp_mov<0x121>(0.0f, v);       // row_ror:1
+    return v;
+}
+
+// ---- activation I/O: raw buffer accesses ------------------------------------------------------------------------------------
+// Every lane touches ONE element per tensor and channel; with plain pointers that is a 64-bit address per (tensor,
+// channel) and lane, and hipcc keeps all of them live across the tile loop (the first build of the backward: 300 VGPRs
+// of spills).  A buffer access splits the address into the resource's base (SGPRs: tensor + batch offset), a scalar
+// offset (SGPR: the wave's channel) and ONE 32-bit lane offset per tensor (the row's channel offset + the token).
+// The host checks that a (channel, token) offset inside one batch element fits 32 bits (ls_offsets_ok).
+// Kernel arguments arrive as s_load_dwordx16 tuples; when SGPRs run short hipcc spills whole tuples to VGPR lanes and
+// reloads all sixteen (v_readlane) for every field it touches inside the loops.  Values that are used in the loops are
+// therefore copied out once, through a VGPR and v_readfirstlane, into scalars of their own.
+__device__ __forceinline__ unsigned ls_own(unsigned v) {
+    asm volatile("" : "+v"(v));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ int ls_own(int v) { return (int)ls_own((unsigned)v); }
+template <typename P> __device__ __forceinline__ P* ls_own(P* q) {
+    const uint64_t a = reinterpret_cast<uint64_t>(q);
+    return reinterpret_cast<P*>(((uint64_t)ls_own((unsigned)(a >> 32)) << 32) | ls_own((unsigned)a));
+}
+typedef __amdgpu_buffer_rsrc_t ls_rsrc;
+__device__ __forceinline__ ls_rsrc ls_make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, -1, 0x00020000);
+}
+template <typename T> struct LsElem;
+template <> struct LsElem<float> {
+    static __device__ __forceinline__ float ld(ls_rsrc r, unsigned voff, unsigned soff) {
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    }
+    static __device__ __forceinline__ void st(ls_rsrc r, unsigned voff, unsigned soff, float v) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+    }
+};
+template <> struct LsElem<bf16_t> {
+    static __device__ __forceinline__ float ld(ls_rsrc r, unsigned voff, unsigned soff) {
+        return __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0) << 16);
+    }
+    static __device__ __forceinline__ void st(ls_rsrc r, unsigned voff, unsigned soff, float v) {
+        union { bf16_t h; unsigned short u; } c;
+        c.h = from_f32<bf16_t>(v);
+        __builtin_amdgcn_raw_buffer_store_b16(c.u, r, voff, soff, 0);
+    }
+};
+template <> struct LsElem<f16_t> {
+    static __device__ __forceinline__ float ld(ls_rsrc r, unsigned voff, unsigned soff) {
+        union { unsigned short u; f16_t h; } c;
+        c.u = __builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0);
+        return static_cast<float>(c.h);
+    }
+    static __device__ __forceinline__ void st(ls_rsrc r, unsigned voff, unsigned soff, float v) {
+        union { f16_t h; unsigned short u; } c;
+        c.h = from_f32<f16_t>(v);
+        __builtin_amdgcn_raw_buffer_store_b16(c.u, r, voff, soff, 0);
+    }
+};
+// One tensor of shape (batch, dim, seqlen): resource of this batch element, channel stride in bytes, and the lane's own
+// offset (its row's first channel + its token of the current tile).  Loads are unconditional (a load under a divergent
+// branch turns every later wait into a full drain): a lane that is off reads the element at offset 0 and drops it.
+// The kernel arguments, re-read through a pointer the compiler cannot see through (scalar loads out of the constant
+// cache, merged per step): a tensor's base / strides are then live only around its access instead of sitting in
+// SGPRs for the whole kernel -- twelve tensors do not fit, and hipcc spilled them to VGPR lanes (v_readlane for every
+// access: 525 per tile in the first build).
+typedef const __attribute__((address_space(4))) char* ls_kargs;
+__device__ __forceinline__ ls_kargs ls_fresh_kargs() {
+    ls_kargs q = (ls_kargs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(q));
+    return q;
+}
+template <typename V> __device__ __forceinline__ V ls_karg(ls_kargs q, int off) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) V*>(q + off);
+}
+#define LS_OFF(S, fld) ((int)__builtin_offsetof(S, fld))
+
+template <typename T> struct LsTensor {
+    int off_ptr, off_bs;           // byte offsets of the pointer and of {batch stride, channel stride} in the kernel arguments
+    int b;                         // batch element
+    unsigned lane_off;             // bytes: (this row's first channel - the wave's first channel) * channel stride
+    __device__ __forceinline__ void init(int off_ptr_, int off_bs_, int b_, int64_t d_stride, int row_ch) {
+        off_ptr = off_ptr_; off_bs = off_bs_; b = b_;
+        lane_off = (unsigned)row_ch * (unsigned)d_stride * (unsigned)sizeof(T);
+    }
+    struct Acc { ls_rsrc r; unsigned soff; };
+    // chu: wave-uniform channel (the wave's first channel + c, clamped to a valid one).  The resource's size field carries
+    // chu so that it is rebuilt (scalar moves) per access instead of being kept.
+    __device__ __forceinline__ Acc acc(ls_kargs q, int chu) const {
+        const T* ptr = ls_karg<const T*>(q, off_ptr);
+        const int64_t bs = ls_karg<int64_t>(q, off_bs), ds = ls_karg<int64_t>(q, off_bs + 8);
+        Acc a;
+        a.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(ptr + (int64_t)b * bs), (short)0, (int)(0xffff0000u + (unsigned)chu), 0x00020000);
+        a.soff = (unsigned)chu * ((unsigned)ds * (unsigned)sizeof(T));
+        return a;
+    }
+    // t: this lane's token
+    __device__ __forceinline__ float ld(ls_kargs q, int chu, int t, bool ok) const { const float v = ld_raw(q, chu, t, ok); return ok ? v : 0.0f; }
+    __device__ __forceinline__ float ld_raw(ls_kargs q, int chu, int t, bool ok) const {
+        const Acc a = acc(q, chu);
+        return LsElem<T>::ld(a.r, ok ? lane_off + (unsigned)t * (unsigned)sizeof(T) : 0u, a.soff);
+    }
+    // Stores are issued by every lane: a store under a divergent branch makes hipcc's s_waitcnt counting give up (every
+    // later wait becomes vmcnt(0), which also waits for the NEXT step's prefetched loads).  A lane that is off gets an
+    // offset beyond the resource's size: the buffer range check (voffset >= num_records) drops its store.
+    __device__ __forceinline__ void st(ls_kargs q, int chu, int t, bool ok, float v) const {
+        const Acc a = acc(q, chu);
+        LsElem<T>::st(a.r, ok ? lane_off + (unsigned)t * (unsigned)sizeof(T) : 0xfffffff0u, a.soff, v);
+    }
+};
+// The same with base and stride held in SGPRs of their own for the whole kernel: for the few tensors that are LOADED at
+// the top of every step, where the latency of the scalar loads above would be exposed.
+template <typename T> struct LsTensorR {
+    const T* base;                 // this batch element's (channel 0, token 0), wave-uniform
+    unsigned dstride;              // bytes between channels
+    unsigned lane_off;
+    __device__ __forceinline__ void init(const void* p, int64_t batch_off, int64_t d_stride, int row_ch) {
+        base = ls_own(static_cast<const T*>(p) + batch_off);
+        dstride = ls_own((unsigned)d_stride * (unsigned)sizeof(T));
+        lane_off = (unsigned)row_ch * dstride;
+    }
+    __device__ __forceinline__ float ld(int chu, int t, bool ok) const { const float v = ld_raw(chu, t, ok); return ok ? v : 0.0f; }
+    // without the final select: for values that are requested a step ahead -- the select would be scheduled right behind
+    // the load and wait for it; the consumer applies `ok` when it uses the value
+    __device__ __forceinline__ float ld_raw(int chu, int t, bool ok) const {
+        const ls_rsrc r = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), (short)0, (int)(0xffff0000u + (unsigned)chu), 0x00020000);
+        return LsElem<T>::ld(r, ok ? lane_off + (unsigned)t * (unsigned)sizeof(T) : 0u, (unsigned)chu * dstride);
+    }
+};
+// the checkpoint tensor x (batch, dim, nck, dstate) f32: "token" = (row, state), channel stride = nck * dstate floats
+struct LsCkpt {
+    int off_ptr;
+    unsigned bstride_ch;           // channels per batch element (dim)
+    unsigned dstride;              // bytes between channels
+    int b;
+    unsigned lane_off;
+    __device__ __forceinline__ void init(int off_ptr_, int b_, int dim, int nck, int NS, int row_ch) {
+        off_ptr = off_ptr_; b = b_; bstride_ch = (unsigned)dim;
+        dstride = (unsigned)nck * (unsigned)NS * 4u;
+        lane_off = (unsigned)row_ch * dstride;
+    }
+    __device__ __forceinline__ LsTensor<float>::Acc acc(ls_kargs q, int chu) const {
+        const float* ptr = ls_karg<const float*>(q, off_ptr);
+        LsTensor<float>::Acc a;
+        a.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ptr) + (int64_t)b * bstride_ch * (dstride / 4u), (short)0,
+                                                (int)(0xffff0000u + (unsigned)chu), 0x00020000);
+        a.soff = (unsigned)chu * dstride;
+        return a;
+    }
+    __device__ __forceinline__ float ld(ls_kargs q, int chu, int idx, bool ok) const { const float v = ld_raw(q, chu, idx, ok); return ok ? v : 0.0f; }
+    __device__ __forceinline__ float ld_raw(ls_kargs q, int chu, int idx, bool ok) const {
+        const auto a = acc(q, chu);
+        return LsElem<float>::ld(a.r, ok ? lane_off + (unsigned)idx * 4u : 0u, a.soff);
+    }
+    __device__ __forceinline__ void st(ls_kargs q, int chu, int idx, bool ok, float v) const {
+        const auto a = acc(q, chu);
+        LsElem<float>::st(a.r, ok ? lane_off + (unsigned)idx * 4u : 0xfffffff0u, a.soff, v);
+    }
+};
+
+// 16 consecutive tokens of one row of B or C (this lane's state): resource of the (batch, group) block, lane offset =
+// the state's row.  vec: rows and t0 are 16-byte aligned and the tile is whole; otherwise element loads with a tail predicate.
+// sixteen elements out of 16-byte vectors, without a union (hipcc left the union of some instantiations on the stack)
+template <typename T> struct LsUnpack;
+template <> struct LsUnpack<float> {
+    static __device__ __forceinline__ void run(const u32x4 (&raw)[4], float (&v)[16]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i * 4 + 0] = __uint_as_float(raw[i].x); v[i * 4 + 1] = __uint_as_float(raw[i].y);
+            v[i * 4 + 2] = __uint_as_float(raw[i].z); v[i * 4 + 3] = __uint_as_float(raw[i].w);
+        }
+    }
+};
+template <> struct LsUnpack<bf16_t> {
+    static __device__ __forceinline__ void run(const u32x4 (&raw)[2], float (&v)[16]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned w[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v[i * 8 + q * 2 + 0] = __uint_as_float(w[q] << 16);
+                v[i * 8 + q * 2 + 1] = __uint_as_float(w[q] & 0xffff0000u);
+            }
+        }
+    }
+};
+template <> struct LsUnpack<f16_t> {
+    static __device__ __forceinline__ void run(const u32x4 (&raw)[2], float (&v)[16]) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned w[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const h2 hh = __builtin_bit_cast(h2, w[q]);
+                v[i * 8 + q * 2 + 0] = static_cast<float>(hh.x);
+                v[i * 8 + q * 2 + 1] = static_cast<float>(hh.y);
+            }
+        }
+    }
+};
+
+template <typename T> struct LsRow {
+    int off_ptr, off_bs;           // kernel-argument offsets of the pointer and of {batch stride, group stride, dstate stride}
+    int b, g;
+    unsigned lane_off;             // bytes: state * dstate stride
+    __device__ __forceinline__ void init(int off_ptr_, int off_bs_, int b_, int g_, int64_t n_stride, int n) {
+        off_ptr = off_ptr_; off_bs = off_bs_; b = b_; g = g_;
+        lane_off = (unsigned)n * (unsigned)n_stride * (unsigned)sizeof(T);
+    }
+    __device__ __forceinline__ void load16(ls_kargs q, int t0, int L, bool vec, float (&v)[16]) const {
+        const T* ptr = ls_karg<const T*>(q, off_ptr);
+        const int64_t bs = ls_karg<int64_t>(q, off_bs), gs = ls_karg<int64_t>(q, off_bs + 8);
+        const ls_rsrc r = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(ptr + (int64_t)b * bs + (int64_t)g * gs), (short)0,
+                                                            (int)(0xffff0000u + (unsigned)(t0 & 0xfff0)), 0x00020000);
+        if (vec) {
+            constexpr int NV = (int)sizeof(T);          // 16-byte vectors per 16 elements
+            u32x4 raw[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                raw[i] = __builtin_amdgcn_raw_buffer_load_b128(r, lane_off + (unsigned)i * 16u, (unsigned)t0 * (unsigned)sizeof(T), 0);
+            LsUnpack<T>::run(raw, v);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const bool ok = t0 + k < L;
+                const float x = LsElem<T>::ld(r, lane_off + (ok ? (unsigned)k * (unsigned)sizeof(T) : 0u), (ok ? (unsigned)t0 : 0u) * (unsigned)sizeof(T));
+                v[k] = ok ? x : 0.0f;
+            }
+        }
+    }
+};
+
+// ---- geometry shared by the kernels and the host -----------------------------------------------------------------------
+struct LsSeg {
+    int S, seg_blocks;             // segments, checkpoint blocks (16 * RPS tokens) per segment
+    float* agg;                    // [batch][dim][S][dstate]   pre-pass: the segment's aggregate for zero inflow
+    float* dsum;                   // [batch][dim][S]           pre-pass: the segment's sum of delta (see the kernels)
+    float* gin;                    // [batch][dim][S][dstate]   carry kernel: inflow of segment s
+    int bc_vec;                    // B / C rows may be read with 16-byte vectors
+};
+
+template <int NS> struct LsGeom {
+    static constexpr int RPS = NS / 16;                 // rows per stream
+    static constexpr int SPW = 4 / RPS;                 // streams per wave
+    static constexpr int CPW = SPW * kLsCPR;            // channels per wave
+    static constexpr int CK = 16 * RPS;                 // tokens per checkpoint row of x
+};
+
+// The wave's first channel, re-read through a value the compiler cannot see through: the scalar offsets of the four
+// channels of a tile (8 tensors x 4 channels) would otherwise all be hoisted out of the tile loop and spill.
+__device__ __forceinline__ int ls_fresh_uniform(int& v) {
+    asm volatile("" : "+v"(v));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+// ... and the same value made to depend on `result`: the next channel's loads (whose scalar offsets come from it) cannot
+// be issued before `result` exists, so hipcc cannot sink the recurrences of all four channels of a tile below the four
+// prologues and run them interleaved (it did: 4 x the live registers, 800 bytes of spills per lane).
+__device__ __forceinline__ void ls_tie(int& v, float result) { asm volatile("" : "+v"(v) : "v"(result)); }
+
+// =========================================================================================================================
+// Backward, main kernel.  One loop over (tile, channel) steps, tiles right to left, the row's kLsCPR channels inside a
+// tile.  What a channel carries from tile to tile (the reverse carry, dA, dD, dbias partial sums) lives in wave-private
+// LDS, 4 floats per lane and channel, so the loop body holds ONE channel's registers and is not unrolled over channels
+// (the unrolled first version: 4 x the code, its scalar state spilled to VGPR lanes).  The activations of step i + 1 are
+// requested before step i is computed.
+// =========================================================================================================================
+template <typename T, int NS, bool HAS_Z>
+__global__ void __launch_bounds__(256) ssm_ls_bwd_kernel(const vivim_ssm_bwd_params p, const LsSeg sg) {
+    typedef LsGeom<NS> G;
+    constexpr int RPS = G::RPS, SPW = G::SPW, CPW = G::CPW, CPR = kLsCPR;
+    const vivim_ssm_fwd_params& f = p.f;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), W = blockDim.x >> 6;
+    const int row = lane >> 4, li = lane & 15;
+    const int rs = row % RPS, sw = row / RPS;
+    const int n = rs * 16 + li;                               // this lane's state
+    const int tk = ((li & 1) << 3) | ((li & 2) << 1) | ((li & 4) >> 1) | ((li & 8) >> 3);   // this lane's token of a tile
+    const int b = blockIdx.y, seg = blockIdx.z;
+    const int L = ls_own(f.seqlen), cpg = f.dim / f.n_groups;
+    const int cpb = W * CPW;                                  // channels per workgroup
+    const int bpg = (cpg + cpb - 1) / cpb;                    // workgroups per B/C group
+    const int g = blockIdx.x / bpg;
+    const int d_end = ls_own((g + 1) * cpg);
+    const int dwave = ls_own(g * cpg + (blockIdx.x - g * bpg) * cpb + wave * CPW);     // first channel of this wave (uniform)
+    const int rowch = sw * CPR;                               // this row's first channel, relative to the wave's
+    const int ntiles = (L + kLsT - 1) / kLsT;
+    const int nck = (ntiles + RPS - 1) / RPS;                 // checkpoint rows of x
+    const int blk_lo = seg * sg.seg_blocks, blk_hi = min(nck, blk_lo + sg.seg_blocks);
+    const int tile_lo = blk_lo * RPS, tile_hi = min(ntiles, blk_hi * RPS);
+    const int t_next = blk_hi * G::CK;                        // first token right of the segment
+    const bool single = ls_own((int)(bpg == 1)) != 0;         // this workgroup is the only contributor to its dB / dC rows
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* slot = smem + ((wave * SPW + sw) * 2 * NS + n) * 16;          // [wave][stream][dB | dC][n][16 tokens]
+    constexpr int NF = 5 + RPS - 1;                           // per-lane fields per channel (+ inner block boundaries, dstate 32 / 64)
+    float* cstate = smem + W * SPW * 2 * NS * 16 + wave * (CPR * NF * kWave) + lane;   // [wave][channel][field][lane]
+    // carried: GCAR, DACC, DDACC, DBIAS; constant: A * log2e of (channel, state).  D and delta_bias are per channel only:
+    // a small table [wave][channel][row][D | bias] behind the per-lane fields (3 workgroups per CU need <= 53 KB each)
+    enum { GCAR = 0, DACC = 1, DDACC = 2, DBIAS = 3, A2F = 4, HSUB = 5 };
+    float* ctab = smem + W * SPW * 2 * NS * 16 + W * (CPR * NF * kWave) + (wave * CPR * 4 + row) * 2;
+
+    typedef vivim_ssm_bwd_params BP;
+    LsTensorR<T> tu, tdl, tdo;                                // loaded first in every step: resident
+    LsTensor<T> tz, to, tdu, tdd, tdz, toz;                   // the rest: through the kernel arguments
+    tu.init(f.u, b * f.u_batch_stride, f.u_d_stride, rowch);
+    tdl.init(f.delta, b * f.delta_batch_stride, f.delta_d_stride, rowch);
+    tdo.init(p.dout, b * p.dout_batch_stride, p.dout_d_stride, rowch);
+    tdu.init(LS_OFF(BP, du), LS_OFF(BP, du_batch_stride), b, p.du_d_stride, rowch);
+    tdd.init(LS_OFF(BP, ddelta), LS_OFF(BP, ddelta_batch_stride), b, p.ddelta_d_stride, rowch);
+    if (HAS_Z) {
+        tz.init(LS_OFF(BP, f.z), LS_OFF(BP, f.z_batch_stride), b, f.z_d_stride, rowch);
+        to.init(LS_OFF(BP, f.out), LS_OFF(BP, f.out_batch_stride), b, f.out_d_stride, rowch);
+        tdz.init(LS_OFF(BP, dz), LS_OFF(BP, dz_batch_stride), b, p.dz_d_stride, rowch);
+        toz.init(LS_OFF(BP, f.out_z), LS_OFF(BP, f.out_z_batch_stride), b, f.out_z_d_stride, rowch);
+    }
+    LsCkpt tx;
+    tx.init(LS_OFF(BP, f.x), b, f.dim, nck, NS, rowch);
+    LsRow<T> rB, rC;
+    rB.init(LS_OFF(BP, f.B), LS_OFF(BP, f.B_batch_stride), b, g, f.B_dstate_stride, n);
+    rC.init(LS_OFF(BP, f.C), LS_OFF(BP, f.C_batch_stride), b, g, f.C_dstate_stride, n);
+    float* __restrict__ dBg = ls_own(static_cast<float*>(p.dB) + b * p.dB_batch_stride + g * p.dB_group_stride);
+    float* __restrict__ dCg = ls_own(static_cast<float*>(p.dC) + b * p.dC_batch_stride + g * p.dC_group_stride);
+    const int dBns = ls_own((int)p.dB_dstate_stride), dCns = ls_own((int)p.dC_dstate_stride);
+    const bool softplus = ls_own((int)f.delta_softplus) != 0, want_oz = HAS_Z && ls_own((int)(f.out_z != nullptr)) != 0;
+    const bool bc_vec = ls_own(sg.bc_vec) != 0;
+
+    // ---- per-channel state: the reverse carry a_{t+1} g_{t+1} of the token that is processed next, and three sums ----
+    for (int c = 0; c < CPR; ++c) {
+        const int d = dwave + rowch + c;
+        const bool cv = d < d_end;
+        const int dc = cv ? d : d_end - 1;
+        const float A2 = static_cast<const float*>(f.A)[dc * f.A_d_stride + n * f.A_dstate_stride] * kLog2e;
+        const float bias = f.delta_bias ? static_cast<const float*>(f.delta_bias)[dc] : 0.0f;
+        const float gin = (sg.S > 1 && cv) ? sg.gin[(((int64_t)b * f.dim + dc) * sg.S + seg) * NS + n] : 0.0f;
+        float dl_nx = 0.0f;                                   // delta of the first token right of the segment
+        if (t_next < L) {
+            const float raw = tdl.ld(min(dwave + c, d_end - 1), t_next, cv) + bias;
+            dl_nx = softplus ? softplus_ref(raw) : raw;
+        }
+        float* cs = cstate + c * NF * kWave;
+        cs[GCAR * kWave] = gin * fast_exp2(dl_nx * A2);
+        cs[DACC * kWave] = 0.0f; cs[DDACC * kWave] = 0.0f; cs[DBIAS * kWave] = 0.0f;
+        cs[A2F * kWave] = A2;
+        ctab[c * 8 + 0] = f.D ? static_cast<const float*>(f.D)[dc] : 0.0f;      // every lane of the row writes the same value
+        ctab[c * 8 + 1] = bias;
+    }
+
+    // what a step reads from memory for this lane: requested one step ahead
+    struct Raw { float uu, raw, dy, zf, of, hin; };
+    auto fetch = [&](int tile, int c) __attribute__((always_inline)) -> Raw {
+        Raw r;
+        const ls_kargs q = ls_fresh_kargs();
+        const int t = tile * kLsT + tk;
+        const int d = dwave + rowch + c;
+        const bool cv = d < d_end;
+        const int chu = min(dwave + c, d_end - 1);
+        const bool ok = cv && t < L && tile >= tile_lo;       // past the segment's last step: nothing is used
+        r.uu = tu.ld_raw(chu, t, ok);
+        r.raw = tdl.ld_raw(chu, t, ok);
+        r.dy = tdo.ld_raw(chu, t, ok);
+        r.zf = 0.0f; r.of = 0.0f;
+        if (HAS_Z) { r.zf = tz.ld_raw(q, chu, t, ok); r.of = to.ld_raw(q, chu, t, ok); }
+        const int blk = tile / RPS;
+        r.hin = tx.ld_raw(q, chu, (blk - 1) * NS + n, blk > 0 && cv && tile >= tile_lo);
+        return r;
+    };
+
+    float Bv[16], Cv[16], dBv[16], dCv[16];
+    Raw nxt = fetch(tile_hi - 1, 0);
+    // The per-token outputs of a step are stored at the START of the next one, between the first use of that step's inputs
+    // and the request for the inputs of the one after: a step's loads then have a whole step to land, and the wait in
+    // front of the first use (hipcc writes vmcnt(0) there, it cannot count across the loop edge) only meets stores that
+    // were issued a step earlier.
+    float p_du = 0.0f, p_dd = 0.0f, p_dz = 0.0f, p_oz = 0.0f;
+    int p_chu = min(dwave, d_end - 1), p_t = 0;
+    bool p_st = false;
+    auto flush = [&]() __attribute__((always_inline)) {
+        const ls_kargs qs = ls_fresh_kargs();
+        if (HAS_Z) {
+            tdz.st(qs, p_chu, p_t, p_st, p_dz);
+            if (want_oz) toz.st(qs, p_chu, p_t, p_st, p_oz);
+        }
+        tdu.st(qs, p_chu, p_t, p_st, p_du);
+        tdd.st(qs, p_chu, p_t, p_st, p_dd);
+    };
+#pragma unroll 1
+    for (int tile = tile_hi - 1; tile >= tile_lo; --tile) {
+        const int t0 = tile * kLsT;
+        const int t = t0 + tk;
+        const bool tv = t < L;
+        const int blk = tile / RPS, j = tile - blk * RPS;
+        {
+            const bool vec = bc_vec && t0 + kLsT <= L;
+            const ls_kargs q = ls_fresh_kargs();
+            rB.load16(q, t0, L, vec, Bv);
+            rC.load16(q, t0, L, vec, Cv);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { dBv[k] = 0.0f; dCv[k] = 0.0f; }
+        ls_arrive(Bv);
+        ls_arrive(Cv);
+#pragma unroll 1
+        for (int c = 0; c < CPR; ++c) {
+            Raw cur = nxt;                                    // as loaded: lanes that are off hold the element at offset 0
+            const int d = dwave + rowch + c;
+            const bool cv = d < d_end;                        // uniform per row
+            const int chu = min(dwave + c, d_end - 1);        // uniform part of the channel, clamped to a valid one
+            const bool ok = cv && tv;
+            cur.uu = ok ? cur.uu : 0.0f; cur.raw = ok ? cur.raw : 0.0f; cur.dy = ok ? cur.dy : 0.0f;
+            if (HAS_Z) { cur.zf = ok ? cur.zf : 0.0f; cur.of = ok ? cur.of : 0.0f; }
+            cur.hin = (cv && blk > 0) ? cur.hin : 0.0f;
+            {   // "used here": the selects must not drift below the next step's loads
+                float u0 = cur.uu, u1 = cur.raw, u2 = cur.dy, u3 = cur.zf, u4 = cur.of, u5 = cur.hin;
+                asm volatile("" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5));
+                cur.uu = u0; cur.raw = u1; cur.dy = u2; cur.zf = u3; cur.of = u4; cur.hin = u5;
+            }
+            flush();                                          // the previous step's outputs
+            nxt = fetch(c + 1 < CPR ? tile : tile - 1, c + 1 < CPR ? c + 1 : 0);
+            const bool st = ok && rs == 0;                    // one row of a stream stores the per-token outputs
+            float* cs = cstate + c * NF * kWave;
+            // ---- this lane's token of channel d ----
+            float dy = cur.dy;
+            if (HAS_Z) {
+                const float sgm = sigmoidf_fast(cur.zf);
+                const float dzv = dy * cur.of * sgm * (1.0f + cur.zf * (1.0f - sgm));        // bwd_kernel.cuh:186-191
+                dy *= cur.zf * sgm;
+                p_dz = dzv;
+                p_oz = cur.of * cur.zf * sgm;                                                 // bwd_kernel.cuh:193-204
+            }
+            const float raw = cur.raw + ctab[c * 8 + 1];
+            float dl = ok ? (softplus ? softplus_ref(raw) : raw) : 0.0f;                     // padded tokens: identity step
+            float w = dl * cur.uu;
+            cs[DDACC * kWave] += dy * cur.uu;
+            ls_settle(dl, w, dy);
+            const float A2 = cs[A2F * kWave];
+            // ---- forward states of the tile, from the checkpoint (dstate 32 / 64: from the block's inner boundaries) ----
+            float h_in = cur.hin;
+            if constexpr (RPS > 1) {
+                if (tile == min(tile_hi, (blk + 1) * RPS) - 1) {  // first tile of this block to be processed: rebuild the
+                    float h = cur.hin;                             // states at the block's inner tile boundaries
+                    const float bias = ctab[c * 8 + 1];
+                    const ls_kargs qs = ls_fresh_kargs();
+                    for (int jj = 0; jj < j; ++jj) {
+                        const int t0j = (blk * RPS + jj) * kLsT, tj = t0j + tk;
+                        const bool okj = cv && tj < L;
+                        float Bj[16];
+                        rB.load16(qs, t0j, L, bc_vec && t0j + kLsT <= L, Bj);
+                        const float uj = tu.ld(chu, tj, okj);
+                        const float rawj = tdl.ld(chu, tj, okj) + bias;
+                        float dlj = okj ? (softplus ? softplus_ref(rawj) : rawj) : 0.0f;
+                        float wj = dlj * uj;
+                        ls_settle(dlj, wj);
+                        sfor<0, 16>([&](auto kc) {
+                            constexpr int k = decltype(kc)::value;
+                            const float a = fast_exp2(tok<k>(dlj) * A2);
+                            h = tok_fma<k>(a * h, wj, Bj[k]);
+                        });
+                        cs[(HSUB + jj) * kWave] = h;          // kept per channel until the block's first tile is done
+                    }
+                }
+                if (j > 0) h_in = cs[(HSUB + j - 1) * kWave];
+            }
+            float a[16], h[16];
+            {
+                float hp = h_in;
+                sfor<0, 16>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    a[k] = fast_exp2(tok<k>(dl) * A2);
+                    hp = tok_fma<k>(a[k] * hp, w, Bv[k]);                                  // h_t = a_t h_{t-1} + d_t u_t B_t
+                    h[k] = hp;
+                });
+            }
+            // ---- reverse sweep: g_t = a_{t+1} g_{t+1} + C_t dy_t; ag = a_t g_t is the carry to the left ----
+            float s1[16], s2[16], z1[8], z2[8], w1[4], w2[4], v1[2], v2[2], S1, S2;
+            {
+                float ag = cs[GCAR * kWave], dAc = cs[DACC * kWave];
+                sfor_down<16>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    const float gk = tok_fma<k>(ag, dy, Cv[k]);                          // g_t
+                    ag = gk * a[k];
+                    const float x = ag * (k > 0 ? h[k > 0 ? k - 1 : 0] : h_in);          // g_t a_t h_{t-1}
+                    s1[k] = gk * Bv[k];
+                    s2[k] = A2 * x;
+                    dAc = tok_fma<k>(dAc, dl, x);
+                    dBv[k] = tok_fma<k>(dBv[k], w, gk);
+                    dCv[k] = tok_fma<k>(dCv[k], dy, h[k]);
+                    ls_reduce_down<k>(s1, z1, w1, v1, S1, li);
+                    ls_reduce_down<k>(s2, z2, w2, v2, S2, li);
+                });
+                cs[GCAR * kWave] = ag;
+                cs[DACC * kWave] = dAc;
+            }
+            S1 = ls_rows_sum<RPS>(S1);
+            S2 = ls_rows_sum<RPS>(S2);
+            // ---- per-token outputs (this lane's token) ----
+            const float duv = fmaf(dl, S1, ctab[c * 8 + 0] * dy);
+            float ddv = fmaf(cur.uu, S1, S2 * kLn2);                                      // S2 carries A * log2e
+            if (softplus && raw <= 20.0f) ddv *= sigmoidf_fast(raw);                      // bwd_kernel.cuh:439-452
+            cs[DBIAS * kWave] += ok ? ddv : 0.0f;
+            p_du = duv; p_dd = ddv; p_chu = chu; p_t = t; p_st = st;
+        }
+        // ---- dB / dC of the tile: this row's channels are summed; add the rows and waves of the workgroup ----
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            *reinterpret_cast<float4*>(slot + q * 4) = float4{dBv[q * 4], dBv[q * 4 + 1], dBv[q * 4 + 2], dBv[q * 4 + 3]};
+            *reinterpret_cast<float4*>(slot + NS * 16 + q * 4) = float4{dCv[q * 4], dCv[q * 4 + 1], dCv[q * 4 + 2], dCv[q * 4 + 3]};
+        }
+        lds_barrier();
+        {
+            const int nsrc = W * SPW;
+            for (int e = tid; e < 2 * NS * 16; e += blockDim.x) {
+                const float* sp = smem + e;
+                float acc = sp[0];
+                for (int s = 1; s < nsrc; ++s) acc += sp[s * 2 * NS * 16];
+                const int isC = e / (NS * 16), en = (e / 16) % NS, ek = e & 15;
+                if (t0 + ek < L) {
+                    float* dst = isC ? dCg + en * dCns : dBg + en * dBns;
+                    if (single) dst[t0 + ek] = acc;                   // the only contributor: plain store, deterministic
+                    else atomicAdd(dst + t0 + ek, acc);               // two workgroups: still order-independent (a + b)
+                }
+            }
+        }
+        lds_barrier();
+    }
+    flush();
+    // ---- per-channel sums ----
+    for (int c = 0; c < CPR; ++c) {
+        const int d = dwave + rowch + c;
+        const float* cs = cstate + c * NF * kWave;
+        const float sD = ls_row_total(cs[DDACC * kWave]), sb = ls_row_total(cs[DBIAS * kWave]);
+        if (d >= d_end) continue;                             // uniform per row
+        atomicAdd(static_cast<float*>(p.dA) + d * p.dA_d_stride + n * p.dA_dstate_stride, cs[DACC * kWave]);
+        if (li == 0 && rs == 0) {
+            if (p.dD) atomicAdd(static_cast<float*>(p.dD) + d, sD);
+            if (p.ddelta_bias) atomicAdd(static_cast<float*>(p.ddelta_bias) + d, sb);
+        }
+    }
+}
+
+// =========================================================================================================================
+// Backward, pre-pass of the token-axis split: per (batch, channel, segment >= 1, state)
+//   agg  = g at the segment's first token for zero inflow from the right
+//   dsum = sum over the segment of delta_{t+1}
+// Waves are independent (no LDS, no barrier).
+// =========================================================================================================================
+template <typename T, int NS, bool HAS_Z>
+__global__ void __launch_bounds__(256) ssm_ls_bwd_prepass_kernel(const vivim_ssm_bwd_params p, const LsSeg sg) {
+    typedef LsGeom<NS> G;
+    constexpr int RPS = G::RPS, CPW = G::CPW, CPR = kLsCPR;
+    const vivim_ssm_fwd_params& f = p.f;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), W = blockDim.x >> 6;
+    const int row = lane >> 4, li = lane & 15;
+    const int rs = row % RPS, sw = row / RPS;
+    const int n = rs * 16 + li;
+    const int tk = ((li & 1) << 3) | ((li & 2) << 1) | ((li & 4) >> 1) | ((li & 8) >> 3);
+    const int b = blockIdx.y, seg = blockIdx.z + 1;           // segment 0 has no left neighbour to feed
+    const int L = f.seqlen, cpg = f.dim / f.n_groups;
+    const int cpb = W * CPW;
+    const int bpg = (cpg + cpb - 1) / cpb;
+    const int g = blockIdx.x / bpg;
+    const int d_end = (g + 1) * cpg;
+    const int dwave = g * cpg + (blockIdx.x - g * bpg) * cpb + wave * CPW;
+    const int rowch = sw * CPR;
+    if (dwave >= d_end) return;                               // whole waves only
+    const int ntiles = (L + kLsT - 1) / kLsT;
+    const int nck = (ntiles + RPS - 1) / RPS;
+    const int blk_lo = seg * sg.seg_blocks, blk_hi = min(nck, blk_lo + sg.seg_blocks);
+    const int tile_lo = blk_lo * RPS, tile_hi = min(ntiles, blk_hi * RPS);
+    const int t_next = blk_hi * G::CK;
+    const float* __restrict__ Ap = static_cast<const float*>(f.A);
+    const float* __restrict__ biasp = static_cast<const float*>(f.delta_bias);
+    typedef vivim_ssm_bwd_params BP;
+    LsTensor<T> tdl, tdo, tz;
+    tdl.init(LS_OFF(BP, f.delta), LS_OFF(BP, f.delta_batch_stride), b, f.delta_d_stride, rowch);
+    tdo.init(LS_OFF(BP, dout), LS_OFF(BP, dout_batch_stride), b, p.dout_d_stride, rowch);
+    if (HAS_Z) tz.init(LS_OFF(BP, f.z), LS_OFF(BP, f.z_batch_stride), b, f.z_d_stride, rowch);
+    LsRow<T> rC;
+    rC.init(LS_OFF(BP, f.C), LS_OFF(BP, f.C_batch_stride), b, g, f.C_dstate_stride, n);
+
+    float A2[CPR], gk[CPR], ag[CPR], dsum[CPR];            // g_t of the last token done, and a_t g_t
+#pragma unroll
+    for (int c = 0; c < CPR; ++c) {
+        const int dc = min(dwave + rowch + c, d_end - 1);
+        A2[c] = Ap[dc * f.A_d_stride + n * f.A_dstate_stride] * kLog2e;
+        gk[c] = 0.0f; ag[c] = 0.0f; dsum[c] = 0.0f;
+    }
+    int tokv = dwave;
+    for (int tile = tile_hi - 1; tile >= tile_lo; --tile) {
+        const int t0 = tile * kLsT;
+        const int t = t0 + tk;
+        const bool tv = t < L;
+        float Cv[16];
+        rC.load16(ls_fresh_kargs(), t0, L, sg.bc_vec && t0 + kLsT <= L, Cv);
+#pragma unroll
+        for (int c = 0; c < CPR; ++c) {
+            const int dw = ls_fresh_uniform(tokv);
+            const int d = dw + rowch + c;
+            const bool cv = d < d_end;
+            const int dc = cv ? d : d_end - 1;
+            const int chu = min(dw + c, d_end - 1);
+            const bool ok = cv && tv;
+            const ls_kargs q = ls_fresh_kargs();
+            const float raw = tdl.ld(q, chu, t, ok) + (biasp ? biasp[dc] : 0.0f);
+            float dy = tdo.ld(q, chu, t, ok);
+            if (HAS_Z) {
+                const float zf = tz.ld(q, chu, t, ok);
+                dy *= zf * sigmoidf_fast(zf);
+            }
+            float dl = ok ? (f.delta_softplus ? softplus_ref(raw) : raw) : 0.0f;
+            dsum[c] += (t == blk_lo * G::CK) ? 0.0f : dl;    // sum of delta over the segment minus its first token's
+            ls_settle(dl, dy);
+            float gg = gk[c], aa = ag[c];
+            sfor_down<16>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                gg = tok_fma<k>(aa, dy, Cv[k]);
+                aa = gg * fast_exp2(tok<k>(dl) * A2[c]);
+            });
+            gk[c] = gg; ag[c] = aa;
+            ls_tie(tokv, aa);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CPR; ++c) {
+        const int d = dwave + rowch + c;
+        if (d >= d_end) continue;
+        sg.agg[(((int64_t)b * f.dim + d) * sg.S + seg) * NS + n] = gk[c];
+        float dl_nx = 0.0f;
+        if (t_next < L) {
+            const float raw = tdl.ld(ls_fresh_kargs(), min(dwave + c, d_end - 1), t_next, true) + (biasp ? biasp[d] : 0.0f);
+            dl_nx = f.delta_softplus ? softplus_ref(raw) : raw;
+        }
+        const float tot = ls_row_total(dsum[c]) + dl_nx;
+        if (li == 0 && rs == 0) sg.dsum[((int64_t)b * f.dim + d) * sg.S + seg] = tot;
+    }
+}
+
+// gin[s-1] = exp2(A2 * dsum[s]) * gin[s] + agg[s], right to left (reverse == true), or
+// gin[s+1] = exp2(A2 * dsum[s]) * gin[s] + agg[s], left to right (forward): one thread per (batch, channel, state).
+// The chain's operands do not depend on the chain: they are fetched 16 segments at a time, all loads in flight
+// together (a dependent walk over global memory costs one memory latency per segment).
+template <bool REVERSE>
+__global__ void __launch_bounds__(256) ssm_ls_carry_kernel(const float* __restrict__ A, int64_t A_d_stride, int64_t A_n_stride,
+                                                           int batch, int dim, int N, const LsSeg sg) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)batch * dim * N) return;
+    const int n = (int)(i % N);
+    const int64_t bd = i / N;
+    const int dch = (int)(bd % dim);
+    const float A2 = A[dch * A_d_stride + n * A_n_stride] * kLog2e;
+    const int S = sg.S;
+    float gcur = 0.0f;
+    sg.gin[(bd * S + (REVERSE ? S - 1 : 0)) * N + n] = 0.0f;
+    // REVERSE: s runs S-1 .. 1 and writes s-1;  forward: s runs 0 .. S-2 and writes s+1
+    for (int i0 = 0; i0 < S - 1; i0 += 16) {
+        float ag[16], ds[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int idx = i0 + q;
+            const int s = REVERSE ? S - 1 - idx : idx;
+            const bool ok = idx < S - 1;
+            ag[q] = ok ? sg.agg[(bd * S + s) * N + n] : 0.0f;
+            ds[q] = ok ? sg.dsum[bd * S + s] : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int idx = i0 + q;
+            if (idx < S - 1) {
+                const int s = REVERSE ? S - 1 - idx : idx;
+                gcur = fmaf(fast_exp2(A2 * ds[q]), gcur, ag[q]);
+                sg.gin[(bd * S + (REVERSE ? s - 1 : s + 1)) * N + n] = gcur;
+            }
+        }
+    }
+}
+
+// =========================================================================================================================
+// Forward: PASS 1 (end state of a segment for zero inflow, sum of delta) and PASS 2 (outputs and checkpoints)
+// =========================================================================================================================
+template <typename T, int NS, int PASS, bool HAS_Z>
+__global__ void __launch_bounds__(256) ssm_ls_fwd_kernel(const vivim_ssm_fwd_params p, const LsSeg sg) {
+    typedef LsGeom<NS> G;
+    constexpr int RPS = G::RPS, CPW = G::CPW, CPR = kLsCPR;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), W = blockDim.x >> 6;
+    const int row = lane >> 4, li = lane & 15;
+    const int rs = row % RPS, sw = row / RPS;
+    const int n = rs * 16 + li;
+    const int tk = ((li & 1) << 3) | ((li & 2) << 1) | ((li & 4) >> 1) | ((li & 8) >> 3);
+    const int b = blockIdx.y, seg = blockIdx.z;
+    const int L = p.seqlen, cpg = p.dim / p.n_groups;
+    const int cpb = W * CPW;
+    const int bpg = (cpg + cpb - 1) / cpb;
+    const int g = blockIdx.x / bpg;
+    const int d_end = (g + 1) * cpg;
+    const int dwave = g * cpg + (blockIdx.x - g * bpg) * cpb + wave * CPW;
+    const int rowch = sw * CPR;
+    if (dwave >= d_end) return;
+    const int ntiles = (L + kLsT - 1) / kLsT;
+    const int nck = (ntiles + RPS - 1) / RPS;
+    const int blk_lo = seg * sg.seg_blocks, blk_hi = min(nck, blk_lo + sg.seg_blocks);
+    const int tile_lo = blk_lo * RPS, tile_hi = min(ntiles, blk_hi * RPS);
+    if (PASS == 1 && seg == sg.S - 1) return;                 // the last segment feeds nobody
+    const float* __restrict__ Ap = static_cast<const float*>(p.A);
+    const float* __restrict__ Dp = static_cast<const float*>(p.D);
+    const float* __restrict__ biasp = static_cast<const float*>(p.delta_bias);
+    typedef vivim_ssm_fwd_params FP;
+    LsTensor<T> tu, tdl, tz, to, toz;
+    tu.init(LS_OFF(FP, u), LS_OFF(FP, u_batch_stride), b, p.u_d_stride, rowch);
+    tdl.init(LS_OFF(FP, delta), LS_OFF(FP, delta_batch_stride), b, p.delta_d_stride, rowch);
+    if (PASS == 2) {
+        to.init(LS_OFF(FP, out), LS_OFF(FP, out_batch_stride), b, p.out_d_stride, rowch);
+        if (HAS_Z) {
+            tz.init(LS_OFF(FP, z), LS_OFF(FP, z_batch_stride), b, p.z_d_stride, rowch);
+            toz.init(LS_OFF(FP, out_z), LS_OFF(FP, out_z_batch_stride), b, p.out_z_d_stride, rowch);
+        }
+    }
+    LsCkpt tx;
+    tx.init(LS_OFF(FP, x), b, p.dim, nck, NS, rowch);
+    LsRow<T> rB, rC;
+    rB.init(LS_OFF(FP, B), LS_OFF(FP, B_batch_stride), b, g, p.B_dstate_stride, n);
+    rC.init(LS_OFF(FP, C), LS_OFF(FP, C_batch_stride), b, g, p.C_dstate_stride, n);
+
+    float A2[CPR], h[CPR], dsum[CPR];
+#pragma unroll
+    for (int c = 0; c < CPR; ++c) {
+        const int d = dwave + rowch + c;
+        const bool cv = d < d_end;
+        const int dc = cv ? d : d_end - 1;
+        A2[c] = Ap[dc * p.A_d_stride + n * p.A_dstate_stride] * kLog2e;
+        h[c] = (PASS == 2 && sg.S > 1 && cv) ? sg.gin[(((int64_t)b * p.dim + dc) * sg.S + seg) * NS + n] : 0.0f;
+        dsum[c] = 0.0f;
+    }
+    int tokv = dwave;
+    for (int tile = tile_lo; tile < tile_hi; ++tile) {
+        const int t0 = tile * kLsT;
+        const int t = t0 + tk;
+        const bool tv = t < L;
+        float Bv[16], Cv[16];
+        {
+            const bool vec = sg.bc_vec && t0 + kLsT <= L;
+            const ls_kargs q = ls_fresh_kargs();
+            rB.load16(q, t0, L, vec, Bv);
+            if (PASS == 2) rC.load16(q, t0, L, vec, Cv);
+        }
+        const bool ck_row = PASS == 2 && (((tile + 1) % RPS) == 0 || tile == ntiles - 1);   // a checkpoint row ends here
+#pragma unroll
+        for (int c = 0; c < CPR; ++c) {
+            const int dw = ls_fresh_uniform(tokv);
+            const int d = dw + rowch + c;
+            const bool cv = d < d_end;
+            const int dc = cv ? d : d_end - 1;
+            const int chu = min(dw + c, d_end - 1);
+            const bool ok = cv && tv;
+            const bool st = ok && rs == 0;
+            const ls_kargs q = ls_fresh_kargs();
+            const float uu = tu.ld(q, chu, t, ok);
+            const float raw = tdl.ld(q, chu, t, ok) + (biasp ? biasp[dc] : 0.0f);
+            float zf = 0.0f;
+            if (PASS == 2 && HAS_Z) zf = tz.ld(q, chu, t, ok);
+            float dl = ok ? (p.delta_softplus ? softplus_ref(raw) : raw) : 0.0f;           // fwd_kernel.cuh:153-156
+            float w = dl * uu;
+            dsum[c] += dl;
+            ls_settle(dl, w);
+            float hh = h[c];
+            if (PASS == 1) {
+                sfor<0, 16>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    const float a = fast_exp2(tok<k>(dl) * A2[c]);                        // fwd_kernel.cuh:216
+                    hh = tok_fma<k>(a * hh, w, Bv[k]);
+                });
+                h[c] = hh;
+                ls_tie(tokv, hh);
+            } else {
+                float s[16], z[8], ww[4], v[2], y;
+                sfor<0, 16>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    const float a = fast_exp2(tok<k>(dl) * A2[c]);
+                    hh = tok_fma<k>(a * hh, w, Bv[k]);
+                    s[k] = hh * Cv[k];                                                     // fwd_kernel.cuh:256-265
+                    ls_reduce_up<k>(s, z, ww, v, y, li);
+                });
+                h[c] = hh;
+                y = ls_rows_sum<RPS>(y);
+                const float o = fmaf(Dp ? Dp[dc] : 0.0f, uu, y);
+                to.st(q, chu, t, st, o);
+                if (HAS_Z) toz.st(q, chu, t, st, o * zf * sigmoidf_fast(zf));                 // fwd_kernel.cuh:280-298
+                if (ck_row) tx.st(q, chu, (tile / RPS) * NS + n, cv, hh);
+                ls_tie(tokv, hh + y);
+            }
+        }
+    }
+    if (PASS == 1) {
+#pragma unroll
+        for (int c = 0; c < CPR; ++c) {
+            const int d = dwave + rowch + c;
+            if (d >= d_end) continue;
+            sg.agg[(((int64_t)b * p.dim + d) * sg.S + seg) * NS + n] = h[c];
+            const float tot = ls_row_total(dsum[c]);
+            if (li == 0 && rs == 0) sg.dsum[((int64_t)b * p.dim + d) * sg.S + seg] = tot;
+        }
+    }
+}
+
+// =========================================================================================================================
+// Host side
+// =========================================================================================================================
+static int ls_cu_count() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = 256;
+        return v;
+    }();
+    return n;
+}
+
+// Shape-only test (the checkpoint layout of `x` follows from it, so forward and backward must agree without looking at
+// pointers): variable B / C and a state count that fills whole rows.
+bool ls_shape_ok(const vivim_ssm_fwd_params& f) {
+    return f.is_variable_B && f.is_variable_C && (f.dstate == 16 || f.dstate == 32 || f.dstate == 64) &&
+           f.dim % f.n_groups == 0;
+}
+int ls_ckpt_len(const vivim_ssm_fwd_params& f) { return 16 * (f.dstate / 16); }
+
+// Workgroup width of the backward: 16 * W channels (dstate 16) of one group share the dB / dC reduction.
+static int ls_bwd_waves(const vivim_ssm_fwd_params& f) {
+    const int cpw = (4 / (f.dstate / 16)) * kLsCPR;
+    const int cpg = f.dim / f.n_groups;
+    int w = (cpg + cpw - 1) / cpw;
+    return w > 4 ? 4 : w;
+}
+
+// Token-axis cut.  All workgroups of a launch take about the same time, so the launch runs in rounds of the resident
+// workgroups; one workgroup over a whole number of rounds costs a full extra round (the first build cut cfg 2 into 774
+// workgroups for 768 slots and took twice the time).  So: as many segments as FIT in `slots` waves (a whole number of
+// rounds when even one segment does not fit), whole checkpoint blocks per segment, at least `min_blocks` of them so that a
+// segment's prologue and the pre-pass stay a small part of it.
+static void ls_segmentation(const vivim_ssm_fwd_params& f, int waves_per_seg, int slots, int min_blocks, int& S, int& seg_blocks) {
+    const int ck = ls_ckpt_len(f);
+    const int nck = (f.seqlen + ck - 1) / ck;
+    int s = slots / waves_per_seg;                             // one round
+    const int smax = nck / min_blocks;
+    if (s > smax) s = smax;
+    if (s > 512) s = 512;
+    if (s < 1) s = 1;
+    seg_blocks = (nck + s - 1) / s;
+    S = (nck + seg_blocks - 1) / seg_blocks;
+}
+
+// resident waves per CU: the backward at 3 waves per SIMD (<= 168 VGPRs, 52.5 KB of LDS per 4-wave workgroup), the
+// forward / pre-pass kernels at 8 (<= 64 VGPRs) or 7
+static void ls_bwd_plan(const vivim_ssm_fwd_params& f, int& W, int& S, int& seg_blocks) {
+    W = ls_bwd_waves(f);
+    const int cpw = (4 / (f.dstate / 16)) * kLsCPR;
+    const int cpg = f.dim / f.n_groups;
+    const int bpg = (cpg + W * cpw - 1) / (W * cpw);
+    const int waves_per_seg = bpg * W * f.n_groups * f.batch;
+    ls_segmentation(f, waves_per_seg, ls_cu_count() * 12, 4, S, seg_blocks);
+}
+static void ls_fwd_plan(const vivim_ssm_fwd_params& f, int& S, int& seg_blocks) {
+    const int cpw = (4 / (f.dstate / 16)) * kLsCPR;
+    const int cpg = f.dim / f.n_groups;
+    const int waves_per_seg = ((cpg + 4 * cpw - 1) / (4 * cpw)) * 4 * f.n_groups * f.batch;    // whole 4-wave workgroups
+    ls_segmentation(f, waves_per_seg, ls_cu_count() * 28, 4, S, seg_blocks);
+}
+
+size_t ls_bwd_workspace_bytes(const vivim_ssm_fwd_params& f) {
+    int W, S, sb;
+    ls_bwd_plan(f, W, S, sb);
+    if (S <= 1) return 0;
+    return (size_t)f.batch * f.dim * S * (2 * f.dstate + 1) * sizeof(float);
+}
+size_t ls_fwd_workspace_bytes(const vivim_ssm_fwd_params& f) {
+    int S, sb;
+    ls_fwd_plan(f, S, sb);
+    if (S <= 1) return 0;
+    return (size_t)f.batch * f.dim * S * (2 * f.dstate + 1) * sizeof(float);
+}
+
+static bool ls_bc_vec(const vivim_ssm_fwd_params& f) {
+    const int64_t epv = f.itype == VIVIM_F32 ? 4 : 8;
+    auto al = [&](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    auto st = [&](int64_t e) { return e % epv == 0; };
+    return al(f.B) && al(f.C) && st(f.B_batch_stride) && st(f.B_group_stride) && st(f.B_dstate_stride) &&
+           st(f.C_batch_stride) && st(f.C_group_stride) && st(f.C_dstate_stride);
+}
+
+static void ls_seg_pointers(LsSeg& sg, void* ws, const vivim_ssm_fwd_params& f) {
+    const size_t nbd = (size_t)f.batch * f.dim * sg.S;
+    sg.agg = static_cast<float*>(ws);
+    sg.gin = sg.agg + nbd * f.dstate;
+    sg.dsum = sg.gin + nbd * f.dstate;
+}
+
+template <typename T, int NS>
+static bool launch_ls_bwd(const vivim_ssm_bwd_params& p, hipStream_t stream) {
+    typedef LsGeom<NS> G;
+    const vivim_ssm_fwd_params& f = p.f;
+    int W, S, seg_blocks;
+    ls_bwd_plan(f, W, S, seg_blocks);
+    const int ck = G::CK;
+    const int nck = (f.seqlen + ck - 1) / ck;
+    LsSeg sg = {1, nck, nullptr, nullptr, nullptr, ls_bc_vec(f) ? 1 : 0};
+    const size_t need = ls_bwd_workspace_bytes(f);
+    if (need && p.workspace && (size_t)p.workspace_bytes >= need) {
+        sg.S = S;
+        sg.seg_blocks = seg_blocks;
+        ls_seg_pointers(sg, p.workspace, f);
+    }
+    const int cpg = f.dim / f.n_groups;
+    const int bpg = (cpg + W * G::CPW - 1) / (W * G::CPW);
+    if (sg.S > 1) {
+        const int PW = 4;                                     // independent waves per pre-pass workgroup
+        const int pbpg = (cpg + PW * G::CPW - 1) / (PW * G::CPW);
+        const dim3 gpre(pbpg * f.n_groups, f.batch, sg.S - 1);
+        if (f.z) hipLaunchKernelGGL((ssm_ls_bwd_prepass_kernel<T, NS, true>), gpre, dim3(PW * kWave), 0, stream, p, sg);
+        else     hipLaunchKernelGGL((ssm_ls_bwd_prepass_kernel<T, NS, false>), gpre, dim3(PW * kWave), 0, stream, p, sg);
+        const int64_t nthr = (int64_t)f.batch * f.dim * f.dstate;
+        hipLaunchKernelGGL((ssm_ls_carry_kernel<true>), dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
+                           static_cast<const float*>(f.A), f.A_d_stride, f.A_dstate_stride, f.batch, f.dim, f.dstate, sg);
+    }
+    const dim3 grid(bpg * f.n_groups, f.batch, sg.S);
+    // per wave: 8 KB of dB / dC slots + the channels' state (5 floats per lane and channel; dstate 32 / 64: + the rebuilt
+    // states at the inner tile boundaries of a checkpoint block) + the D / bias table: 52.1 KB for 4 waves at dstate 16
+    const size_t smem = ((size_t)W * G::SPW * 2 * NS * 16 + (size_t)W * kLsCPR * (5 + G::RPS - 1) * kWave + (size_t)W * kLsCPR * 8) * sizeof(float);
+    auto launch = [&](auto kernel) {
+        if (smem > 65536)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(kernel, grid, dim3(W * kWave), smem, stream, p, sg);
+    };
+    if (f.z) launch(ssm_ls_bwd_kernel<T, NS, true>);
+    else     launch(ssm_ls_bwd_kernel<T, NS, false>);
+    return true;
+}
+
+template <typename T, int NS>
+static bool launch_ls_fwd(const vivim_ssm_fwd_params& p, hipStream_t stream) {
+    typedef LsGeom<NS> G;
+    int S, seg_blocks;
+    ls_fwd_plan(p, S, seg_blocks);
+    const int nck = (p.seqlen + G::CK - 1) / G::CK;
+    LsSeg sg = {1, nck, nullptr, nullptr, nullptr, ls_bc_vec(p) ? 1 : 0};
+    const size_t need = ls_fwd_workspace_bytes(p);
+    if (need && p.workspace && (size_t)p.workspace_bytes >= need) {
+        sg.S = S;
+        sg.seg_blocks = seg_blocks;
+        ls_seg_pointers(sg, p.workspace, p);
+    }
+    const int cpg = p.dim / p.n_groups;
+    const int PW = 4;
+    const int bpg = (cpg + PW * G::CPW - 1) / (PW * G::CPW);
+    const dim3 grid(bpg * p.n_groups, p.batch, sg.S), block(PW * kWave);
+    if (sg.S > 1) {
+        hipLaunchKernelGGL((ssm_ls_fwd_kernel<T, NS, 1, false>), grid, block, 0, stream, p, sg);
+        const int64_t nthr = (int64_t)p.batch * p.dim * p.dstate;
+        hipLaunchKernelGGL((ssm_ls_carry_kernel<false>), dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
+                           static_cast<const float*>(p.A), p.A_d_stride, p.A_dstate_stride, p.batch, p.dim, p.dstate, sg);
+    }
+    if (p.z) hipLaunchKernelGGL((ssm_ls_fwd_kernel<T, NS, 2, true>), grid, block, 0, stream, p, sg);
+    else     hipLaunchKernelGGL((ssm_ls_fwd_kernel<T, NS, 2, false>), grid, block, 0, stream, p, sg);
+    return true;
+}
+
+template <typename T> static bool ls_bwd_by_n(const vivim_ssm_bwd_params& p, hipStream_t s) {
+    switch (p.f.dstate) {
+        case 16: return launch_ls_bwd<T, 16>(p, s);
+        case 32: return launch_ls_bwd<T, 32>(p, s);
+        case 64: return launch_ls_bwd<T, 64>(p, s);
+    }
+    return false;
+}
+template <typename T> static bool ls_fwd_by_n(const vivim_ssm_fwd_params& p, hipStream_t s) {
+    switch (p.dstate) {
+        case 16: return launch_ls_fwd<T, 16>(p, s);
+        case 32: return launch_ls_fwd<T, 32>(p, s);
+        case 64: return launch_ls_fwd<T, 64>(p, s);
+    }
+    return false;
+}
+
+bool try_ls_bwd(const vivim_ssm_bwd_params& p, hipStream_t stream) {
+    if (!ls_shape_ok(p.f) || p.f.x == nullptr) return false;
+    switch (p.f.itype) {
+        case VIVIM_F32: return ls_bwd_by_n<float>(p, stream);
+        case VIVIM_F16: return ls_bwd_by_n<f16_t>(p, stream);
+        case VIVIM_BF16: return ls_bwd_by_n<bf16_t>(p, stream);
+    }
+    return false;
+}
+bool try_ls_fwd(const vivim_ssm_fwd_params& p, hipStream_t stream) {
+    if (!ls_shape_ok(p)) return false;
+    switch (p.itype) {
+        case VIVIM_F32: return ls_fwd_by_n<float>(p, stream);
+        case VIVIM_F16: return ls_fwd_by_n<f16_t>(p, stream);
+        case VIVIM_BF16: return ls_fwd_by_n<bf16_t>(p, stream);
+    }
+    return false;
+}
+
+}  // namespace vivim

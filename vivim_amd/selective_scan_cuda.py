@@ -20,9 +20,9 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def chunk_len(dtype):
-    """Tokens covered by one row of the checkpoint tensor `x`."""
-    return _lib.lib().vivim_scan_chunk_len(_ITYPE[dtype])
+def chunk_len(P):
+    """Tokens covered by one row of the checkpoint tensor `x` for the problem in `P` (a filled SsmFwdParams)."""
+    return _lib.lib().vivim_scan_ckpt_len(P)
 
 
 def _common_checks(u, delta, A, B, C, D_, z_, delta_bias_):
@@ -95,10 +95,10 @@ def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus):
     batch, dim, seqlen, dstate = dims[:4]
     out = _lib.empty_like(delta)                    # inherits delta's (L, B*L, 1) strides, selective_scan.cpp:311
     out_z = _lib.empty_like(z_) if z_ is not None else None
-    ck = chunk_len(u.dtype)
-    x = _lib.empty((batch, dim, (seqlen + ck - 1) // ck, dstate), torch.float32, u.device)
     P = _lib.SsmFwdParams()
     _fill_fwd(P, u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, dims)
+    ck = chunk_len(P)
+    x = _lib.empty((batch, dim, (seqlen + ck - 1) // ck, dstate), torch.float32, u.device)
     P.out, P.x = out.data_ptr(), x.data_ptr()
     P.out_batch_stride, P.out_d_stride = out.stride(0), out.stride(1)
     if out_z is not None:
@@ -121,7 +121,9 @@ def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softp
     batch, dim, seqlen, dstate, n_groups, var_B, var_C = dims
     _check(dout.dtype == u.dtype and dout.is_cuda and dout.stride(-1) == 1
            and tuple(dout.shape) == (batch, dim, seqlen), "dout must match u (dtype, shape, stride(-1) == 1)")
-    ck = chunk_len(u.dtype)
+    P = _lib.SsmBwdParams()
+    _fill_fwd(P.f, u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, dims)
+    ck = chunk_len(P.f)
     n_chunks = (seqlen + ck - 1) // ck
     if n_chunks > 1:
         _check(x_ is not None, "x (scan checkpoints) is required when seqlen spans several chunks")
@@ -156,8 +158,6 @@ def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softp
     dD = acc[nB + nC + nA:nB + nC + nA + dim] if D_ is not None else None
     ddelta_bias = acc[nB + nC + nA + dim:] if delta_bias_ is not None else None
 
-    P = _lib.SsmBwdParams()
-    _fill_fwd(P.f, u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, dims)
     P.f.x = _ptr(x_)
     if has_z:
         P.f.out = out_.data_ptr()
