@@ -31,8 +31,39 @@ def test_struct_layouts_match():
                                 _lib.StateUpdateParams)):
         assert L.vivim_sizeof(which) == ctypes.sizeof(st)
     assert L.vivim_sizeof(99) == 0
-    assert L.vivim_abi_version() == 5
+    assert L.vivim_abi_version() == 6
     assert L.vivim_scan_chunk_len(_lib.F32) > 0 and L.vivim_scan_chunk_len(_lib.BF16) % 64 == 0
+
+
+def test_checkpoint_length_is_a_function_of_shape_and_tuning():
+    """vivim_scan_ckpt_len: short rows (16 tokens per dstate-16 row) for the shapes the lanes=states backward is chosen for,
+    the long rows otherwise; forward tuning 1-3 (families that write long rows) and 5 / 6 (short rows) override the choice."""
+    L = _lib.lib()
+    s = _lib.SsmFwdParams()
+    s.batch, s.dim, s.n_groups, s.dstate, s.seqlen, s.itype = 2, 64, 1, 16, 1280, _lib.BF16
+    s.is_variable_B = s.is_variable_C = 1
+    s.u_d_stride = s.delta_d_stride = s.B_dstate_stride = s.C_dstate_stride = 1280
+    long_rows = L.vivim_scan_chunk_len(_lib.BF16)
+    prev = L.vivim_set_tuning(0, 0)
+    try:
+        assert L.vivim_scan_ckpt_len(ctypes.byref(s)) == 16
+        s.seqlen = 20480                                  # long rows: the lanes=tokens backward, long checkpoint rows
+        s.u_d_stride = s.delta_d_stride = s.B_dstate_stride = s.C_dstate_stride = 20480
+        assert L.vivim_scan_ckpt_len(ctypes.byref(s)) == long_rows
+        L.vivim_set_tuning(0, 6)
+        assert L.vivim_scan_ckpt_len(ctypes.byref(s)) == 16
+        s.dstate = 64
+        assert L.vivim_scan_ckpt_len(ctypes.byref(s)) == 64
+        s.dstate = 24                                     # not a whole number of 16-lane rows
+        assert L.vivim_scan_ckpt_len(ctypes.byref(s)) == long_rows
+        s.dstate = 16
+        L.vivim_set_tuning(0, 1)
+        assert L.vivim_scan_ckpt_len(ctypes.byref(s)) == long_rows
+        s.is_variable_B = s.is_variable_C = 0
+        L.vivim_set_tuning(0, 0)
+        assert L.vivim_scan_ckpt_len(ctypes.byref(s)) == long_rows
+    finally:
+        L.vivim_set_tuning(0, prev)
 
 
 def test_rejects_before_launch():

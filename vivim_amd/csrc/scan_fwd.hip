@@ -445,25 +445,33 @@ size_t ls_fwd_workspace_bytes(const vivim_ssm_fwd_params&);
 bool try_fwd_chan(const vivim_ssm_fwd_params& p, hipStream_t stream);   // scan_fwd_chan.hip
 size_t fwd_chan_workspace_bytes(const vivim_ssm_fwd_params&);
 
-static bool fwd_tuning_allows_ls() { const int t = tuning_fwd_variant(); return t == 0 || t == 5 || t == 6; }
-int scan_ckpt_len(const vivim_ssm_fwd_params& f) {
-    return (ls_shape_ok(f) && fwd_tuning_allows_ls()) ? ls_ckpt_len(f) : kChunk;
+// Which checkpoint rows a shape gets -- and with them which backward family (the forward families that can write them
+// follow).  Measured on MI355X (tools/kb_round2.sh, profiles/r02_kbench_families.log), lanes = states against the round-1
+// families at dstate 16: the backward wins on short rows (cfg 2 grouped stages 1-3: 273 / 172 / 84 us against 288 / 185 /
+// 149) and loses a few per cent on long ones (L 20480: 592 against 564 us; L 81920: 2214 against 2111), where the
+// lanes = tokens kernel amortises its scans over 512-token steps; at dstate 32 / 64 its extra forward sweep per checkpoint
+// block costs more than it gains (cfg 5: 1018 against 820 us).  Forward tuning 5 / 6 pin the short rows for any such shape.
+static bool ls_plan(const vivim_ssm_fwd_params& f) {
+    if (!ls_shape_ok(f)) return false;
+    const int t = tuning_fwd_variant();
+    if (t == 5 || t == 6) return true;
+    if (t != 0) return false;
+    return f.dstate == 16 && f.seqlen <= 8192;
 }
+int scan_ckpt_len(const vivim_ssm_fwd_params& f) { return ls_plan(f) ? ls_ckpt_len(f) : kChunk; }
 int scan_chunk_len(int) { return kChunk; }
 static_assert(kWave * 4 == kChunk, "generic kernel step must equal the checkpoint chunk");
 
 size_t scan_fwd_workspace_bytes(const vivim_ssm_fwd_params& f) {
-    if (!(ls_shape_ok(f) && fwd_tuning_allows_ls())) return 0;
-    // either family may run (the lanes = channels one also wants aligned rows, known only at launch): ask for the larger
-    const size_t a = fwd_chan_workspace_bytes(f), b = ls_fwd_workspace_bytes(f);
+    // either of two families may run (the lanes = channels one also wants aligned rows, known only at launch): the larger
+    const size_t a = fwd_chan_workspace_bytes(f), b = ls_plan(f) ? ls_fwd_workspace_bytes(f) : 0;
     return a > b ? a : b;
 }
 
 bool ssm_fwd_dispatch(const vivim_ssm_fwd_params& p, hipStream_t s) {
-    if (ls_shape_ok(p) && fwd_tuning_allows_ls()) {
-        if (tuning_fwd_variant() != 6 && try_fwd_chan(p, s)) return true;   // lanes = channels: long, wide problems (or tuning 5)
-        return try_ls_fwd(p, s);                                             // lanes = states
-    }
+    const int tune = tuning_fwd_variant();
+    if (tune != 6 && try_fwd_chan(p, s)) return true;      // lanes = channels: long, wide problems (or tuning 5); either row length
+    if (ls_plan(p)) return try_ls_fwd(p, s);               // lanes = states (short checkpoint rows)
     switch (p.itype) {
         case VIVIM_F32: if (!try_fwd_nsplit<float>(p, s)) launch_fwd<float, 4, 2>(p, s); return true;
         case VIVIM_F16: if (!try_fwd_nsplit<f16_t>(p, s)) launch_fwd<f16_t, 4, 2>(p, s); return true;

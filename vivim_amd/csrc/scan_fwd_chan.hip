@@ -27,8 +27,9 @@ namespace vivim {
 
 constexpr int kChN = 16;           // states (compile time: they live in registers)
 constexpr int kChWaves = 2;        // independent waves per workgroup
-constexpr int kChCk = 16;          // tokens per checkpoint row of x: what the lanes = states backward wants (scan_ls.hip)
 constexpr int kChTT = 16;          // tokens per tile (16-bit: 32-byte row pieces, 9 KB of LDS per wave; fp32: 64-byte, 15 KB)
+
+int scan_ckpt_len(const vivim_ssm_fwd_params&);                          // scan_fwd.hip
 
 struct FwdSeg {
     int S, seg_tiles;              // segments, TT-token tiles per segment
@@ -36,6 +37,7 @@ struct FwdSeg {
     float* dsum;                   // [batch][dim][S]     sum of softplus(delta + bias) over the segment
     const float* BC;               // [batch][groups][Lpad + 1][32]  fp32 token-major B / C (ssm_fwd_bc_kernel)
     int Lpad;
+    int ck;                        // tokens per checkpoint row of x (scan_ckpt_len: 16 for the lanes = states backward, else kChunk)
 };
 
 
@@ -177,7 +179,7 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
     constexpr int NIO = kWave / RPI;                  // instructions per tile and stream
     constexpr int ROWB = RB + 16;                     // padded LDS row, bytes (conflict-free 8/16-byte own-row access)
     constexpr int NARR = PASS == 2 && HAS_Z ? 3 : 2;  // resident tiles: u, delta (, z)
-    constexpr int TB = 4;                             // tokens per compute block (L % TB == 0, kChCk % TB == 0)
+    constexpr int TB = 4;                             // tokens per compute block (L % TB == 0, sg.ck % TB == 0)
     typedef uint32_t __attribute__((ext_vector_type(4))) v4;
     typedef typename Pack<T, TB * (int)sizeof(T)>::type vblk;
     __shared__ __attribute__((aligned(16))) unsigned char lds[kChWaves * NARR * kWave * ROWB];
@@ -213,7 +215,8 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
     const float bias = p.delta_bias ? static_cast<const float*>(p.delta_bias)[d] : 0.0f;
     const bool sp_on = p.delta_softplus;
     const float* __restrict__ bc = sg.BC + (int64_t)(b * p.n_groups + g) * (sg.Lpad + 1) * 32;
-    const int nck = (L + kChCk - 1) / kChCk;
+    const int ck = sg.ck;
+    const int nck = (L + ck - 1) / ck;
     float* __restrict__ xlane = static_cast<float*>(p.x) + ((int64_t)b * p.dim + d) * nck * N;   // per-lane (VGPRs)
 
     // cooperative tile I/O: instruction i moves rows i*16 + lane/4, 16-byte column lane%4
@@ -311,10 +314,10 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
                 if (PASS == 2) yo[k + 1] = y2.x + y2.y;
             }
             if (PASS == 2) {
-                // state after every kChCk tokens and after the last one: always the last token of a block
+                // state after every ck tokens and after the last one: always the last token of a block
                 const int tl = tb + TB - 1;
-                if (((tl + 1) & (kChCk - 1)) == 0 || tl == L - 1) {
-                    float* xr = xlane + (tl / kChCk) * N;
+                if (((tl + 1) & (ck - 1)) == 0 || tl == L - 1) {
+                    float* xr = xlane + (tl / ck) * N;
 #pragma unroll
                     for (int n = 0; n < N; ++n) xr[n] = (n & 1) ? hp[n / 2].y : hp[n / 2].x;
                 }
@@ -443,7 +446,10 @@ static bool fwd_chan_eligible(const vivim_ssm_fwd_params& p, bool shape_only = f
     if (tune != 5) {
         if (tune != 0) return false;
         const int64_t cols = (int64_t)p.batch * (p.dim / kWave);
-        if (cols < 8 || cols * p.seqlen < 110000) return false;
+        // short checkpoint rows (scan_ckpt_len): the alternative is the lanes = states forward, which wins below ~250 k
+        // wave-tokens (cfg 2 grouped stages 1-3: 144 / 93 / 51 us against 151 / 109 / 61; cfg 3 stage 2, 410 k: 361 against 302)
+        const int64_t least = scan_ckpt_len(p) < kChunk ? 250000 : 110000;
+        if (cols < 8 || cols * p.seqlen < least) return false;
     }
     const int64_t epv = p.itype == VIVIM_F32 ? 4 : 8;
     auto al = [&](const void* q) { return shape_only || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -481,7 +487,7 @@ static bool launch_fwd_chan(const vivim_ssm_fwd_params& p, hipStream_t stream) {
     size_t bc_floats;
     const size_t need = fwd_chan_layout(p, TT, S, seg_tiles, Lpad, bc_floats);
     if (!p.workspace || (size_t)p.workspace_bytes < need || (reinterpret_cast<uintptr_t>(p.workspace) & 63)) return false;
-    FwdSeg sg = {S, seg_tiles, nullptr, nullptr, static_cast<const float*>(p.workspace), Lpad};
+    FwdSeg sg = {S, seg_tiles, nullptr, nullptr, static_cast<const float*>(p.workspace), Lpad, scan_ckpt_len(p)};
     if (S > 1) {
         sg.H = static_cast<float*>(p.workspace) + bc_floats;
         sg.dsum = sg.H + (size_t)p.batch * p.dim * S * kChN;

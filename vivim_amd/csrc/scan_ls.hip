@@ -347,6 +347,14 @@ template <typename T> struct LsRow {
         off_ptr = off_ptr_; off_bs = off_bs_; b = b_; g = g_;
         lane_off = (unsigned)n * (unsigned)n_stride * (unsigned)sizeof(T);
     }
+    // one 16-byte piece of a whole, aligned tile: row `pn`, piece `pp` of the row's sizeof(T) pieces
+    __device__ __forceinline__ u32x4 piece(ls_kargs q, int t0, unsigned pn, unsigned pp) const {
+        const T* ptr = ls_karg<const T*>(q, off_ptr);
+        const int64_t bs = ls_karg<int64_t>(q, off_bs), gs = ls_karg<int64_t>(q, off_bs + 8), ns = ls_karg<int64_t>(q, off_bs + 16);
+        const ls_rsrc r = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(ptr + (int64_t)b * bs + (int64_t)g * gs), (short)0,
+                                                            (int)(0xffff0000u + (unsigned)(t0 & 0xfff0)), 0x00020000);
+        return __builtin_amdgcn_raw_buffer_load_b128(r, pn * ((unsigned)ns * (unsigned)sizeof(T)) + pp * 16u, (unsigned)t0 * (unsigned)sizeof(T), 0);
+    }
     __device__ __forceinline__ void load16(ls_kargs q, int t0, int L, bool vec, float (&v)[16]) const {
         const T* ptr = ls_karg<const T*>(q, off_ptr);
         const int64_t bs = ls_karg<int64_t>(q, off_bs), gs = ls_karg<int64_t>(q, off_bs + 8);
@@ -377,6 +385,7 @@ struct LsSeg {
     float* dsum;                   // [batch][dim][S]           pre-pass: the segment's sum of delta (see the kernels)
     float* gin;                    // [batch][dim][S][dstate]   carry kernel: inflow of segment s
     int bc_vec;                    // B / C rows may be read with 16-byte vectors
+    int dbg;                       // DIAGNOSTIC (VIVIM_LS_DBG): 1 skips the backward's tile epilogue, 2 its B / C loads -- wrong results
 };
 
 template <int NS> struct LsGeom {
@@ -405,7 +414,7 @@ __device__ __forceinline__ void ls_tie(int& v, float result) { asm volatile("" :
 // requested before step i is computed.
 // =========================================================================================================================
 template <typename T, int NS, bool HAS_Z>
-__global__ void __launch_bounds__(256) ssm_ls_bwd_kernel(const vivim_ssm_bwd_params p, const LsSeg sg) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NS == 16 ? 3 : 2, 3))) ssm_ls_bwd_kernel(const vivim_ssm_bwd_params p, const LsSeg sg) {
     typedef LsGeom<NS> G;
     constexpr int RPS = G::RPS, SPW = G::SPW, CPW = G::CPW, CPR = kLsCPR;
     const vivim_ssm_fwd_params& f = p.f;
@@ -432,12 +441,17 @@ __global__ void __launch_bounds__(256) ssm_ls_bwd_kernel(const vivim_ssm_bwd_par
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* slot = smem + ((wave * SPW + sw) * 2 * NS + n) * 16;          // [wave][stream][dB | dC][n][16 tokens]
-    constexpr int NF = 5 + RPS - 1;                           // per-lane fields per channel (+ inner block boundaries, dstate 32 / 64)
+    constexpr int NF = 4 + RPS - 1;                           // per-lane fields per channel (+ inner block boundaries, dstate 32 / 64)
     float* cstate = smem + W * SPW * 2 * NS * 16 + wave * (CPR * NF * kWave) + lane;   // [wave][channel][field][lane]
-    // carried: GCAR, DACC, DDACC, DBIAS; constant: A * log2e of (channel, state).  D and delta_bias are per channel only:
-    // a small table [wave][channel][row][D | bias] behind the per-lane fields (3 workgroups per CU need <= 53 KB each)
-    enum { GCAR = 0, DACC = 1, DDACC = 2, DBIAS = 3, A2F = 4, HSUB = 5 };
+    // carried: GCAR, DACC, DDACC, DBIAS.  D and delta_bias are per channel only: a small table [wave][channel][row][D | bias]
+    // behind the per-lane fields; A * log2e of the row's channels stays in registers (3 workgroups per CU: <= 53 KB each)
+    enum { GCAR = 0, DACC = 1, DDACC = 2, DBIAS = 3, HSUB = 4 };
     float* ctab = smem + W * SPW * 2 * NS * 16 + W * (CPR * NF * kWave) + (wave * CPR * 4 + row) * 2;
+    // B / C rows of the NEXT tile, raw: [B | C][state][16 tokens]; filled by the whole workgroup between the two barriers of
+    // a tile's epilogue (the loads are issued a step earlier), read by every wave at the top of the next tile
+    unsigned char* stage = reinterpret_cast<unsigned char*>(smem + W * SPW * 2 * NS * 16 + W * (CPR * NF * kWave) + W * CPR * 8);
+    constexpr int PT = NS * (int)sizeof(T);                   // 16-byte pieces per tensor and tile
+    static_assert(CPR == 4, "the per-channel A registers are selected by hand");
 
     typedef vivim_ssm_bwd_params BP;
     LsTensorR<T> tu, tdl, tdo;                                // loaded first in every step: resident
@@ -465,6 +479,8 @@ __global__ void __launch_bounds__(256) ssm_ls_bwd_kernel(const vivim_ssm_bwd_par
     const bool bc_vec = ls_own(sg.bc_vec) != 0;
 
     // ---- per-channel state: the reverse carry a_{t+1} g_{t+1} of the token that is processed next, and three sums ----
+    float A2r[CPR];
+#pragma unroll
     for (int c = 0; c < CPR; ++c) {
         const int d = dwave + rowch + c;
         const bool cv = d < d_end;
@@ -480,7 +496,7 @@ __global__ void __launch_bounds__(256) ssm_ls_bwd_kernel(const vivim_ssm_bwd_par
         float* cs = cstate + c * NF * kWave;
         cs[GCAR * kWave] = gin * fast_exp2(dl_nx * A2);
         cs[DACC * kWave] = 0.0f; cs[DDACC * kWave] = 0.0f; cs[DBIAS * kWave] = 0.0f;
-        cs[A2F * kWave] = A2;
+        A2r[c] = A2;
         ctab[c * 8 + 0] = f.D ? static_cast<const float*>(f.D)[dc] : 0.0f;      // every lane of the row writes the same value
         ctab[c * 8 + 1] = bias;
     }
@@ -506,6 +522,7 @@ __global__ void __launch_bounds__(256) ssm_ls_bwd_kernel(const vivim_ssm_bwd_par
     };
 
     float Bv[16], Cv[16], dBv[16], dCv[16];
+    bool staged = false;
     Raw nxt = fetch(tile_hi - 1, 0);
     // The per-token outputs of a step are stored at the START of the next one, between the first use of that step's inputs
     // and the request for the inputs of the one after: a step's loads then have a whole step to land, and the wait in
@@ -529,7 +546,17 @@ __global__ void __launch_bounds__(256) ssm_ls_bwd_kernel(const vivim_ssm_bwd_par
         const int t = t0 + tk;
         const bool tv = t < L;
         const int blk = tile / RPS, j = tile - blk * RPS;
-        {
+        if (staged) {                                         // this tile's rows were staged during the previous one
+            constexpr int NV = (int)sizeof(T);
+            u32x4 rb[NV], rc[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                rb[i] = *reinterpret_cast<const u32x4*>(stage + (n * NV + i) * 16);
+                rc[i] = *reinterpret_cast<const u32x4*>(stage + (PT + n * NV + i) * 16);
+            }
+            LsUnpack<T>::run(rb, Bv);
+            LsUnpack<T>::run(rc, Cv);
+        } else {
             const bool vec = bc_vec && t0 + kLsT <= L;
             const ls_kargs q = ls_fresh_kargs();
             rB.load16(q, t0, L, vec, Bv);
@@ -539,6 +566,8 @@ __global__ void __launch_bounds__(256) ssm_ls_bwd_kernel(const vivim_ssm_bwd_par
         for (int k = 0; k < 16; ++k) { dBv[k] = 0.0f; dCv[k] = 0.0f; }
         ls_arrive(Bv);
         ls_arrive(Cv);
+        const bool stage_next = W == 4 && bc_vec && tile - 1 >= tile_lo;   // (a tile left of another one is whole)
+        u32x4 sb = {0u, 0u, 0u, 0u}, sc = {0u, 0u, 0u, 0u};
 #pragma unroll 1
         for (int c = 0; c < CPR; ++c) {
             Raw cur = nxt;                                    // as loaded: lanes that are off hold the element at offset 0
@@ -556,6 +585,13 @@ __global__ void __launch_bounds__(256) ssm_ls_bwd_kernel(const vivim_ssm_bwd_par
             }
             flush();                                          // the previous step's outputs
             nxt = fetch(c + 1 < CPR ? tile : tile - 1, c + 1 < CPR ? c + 1 : 0);
+            if (c == CPR - 1 && stage_next) {                 // the next tile's B / C rows: one 16-byte piece of each per thread
+                const ls_kargs q = ls_fresh_kargs();
+                const bool mine = tid < PT;
+                const unsigned pn = (unsigned)tid / (unsigned)sizeof(T), pp = (unsigned)tid % (unsigned)sizeof(T);
+                sb = rB.piece(q, (tile - 1) * kLsT, mine ? pn : 0u, mine ? pp : 0u);
+                sc = rC.piece(q, (tile - 1) * kLsT, mine ? pn : 0u, mine ? pp : 0u);
+            }
             const bool st = ok && rs == 0;                    // one row of a stream stores the per-token outputs
             float* cs = cstate + c * NF * kWave;
             // ---- this lane's token of channel d ----
@@ -572,7 +608,7 @@ __global__ void __launch_bounds__(256) ssm_ls_bwd_kernel(const vivim_ssm_bwd_par
             float w = dl * cur.uu;
             cs[DDACC * kWave] += dy * cur.uu;
             ls_settle(dl, w, dy);
-            const float A2 = cs[A2F * kWave];
+            const float A2 = c == 0 ? A2r[0] : c == 1 ? A2r[1] : c == 2 ? A2r[2] : A2r[3];
             // ---- forward states of the tile, from the checkpoint (dstate 32 / 64: from the block's inner boundaries) ----
             float h_in = cur.hin;
             if constexpr (RPS > 1) {
@@ -613,7 +649,7 @@ __global__ void __launch_bounds__(256) ssm_ls_bwd_kernel(const vivim_ssm_bwd_par
             // ---- reverse sweep: g_t = a_{t+1} g_{t+1} + C_t dy_t; ag = a_t g_t is the carry to the left ----
             float s1[16], s2[16], z1[8], z2[8], w1[4], w2[4], v1[2], v2[2], S1, S2;
             {
-                float ag = cs[GCAR * kWave], dAc = cs[DACC * kWave];
+                float ag = cs[GCAR * kWave], dA0 = cs[DACC * kWave], dA1 = 0.0f;
                 sfor_down<16>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
                     const float gk = tok_fma<k>(ag, dy, Cv[k]);                          // g_t
@@ -621,14 +657,14 @@ __global__ void __launch_bounds__(256) ssm_ls_bwd_kernel(const vivim_ssm_bwd_par
                     const float x = ag * (k > 0 ? h[k > 0 ? k - 1 : 0] : h_in);          // g_t a_t h_{t-1}
                     s1[k] = gk * Bv[k];
                     s2[k] = A2 * x;
-                    dAc = tok_fma<k>(dAc, dl, x);
+                    if constexpr (k & 1) dA1 = tok_fma<k>(dA1, dl, x); else dA0 = tok_fma<k>(dA0, dl, x);   // two chains
                     dBv[k] = tok_fma<k>(dBv[k], w, gk);
                     dCv[k] = tok_fma<k>(dCv[k], dy, h[k]);
                     ls_reduce_down<k>(s1, z1, w1, v1, S1, li);
                     ls_reduce_down<k>(s2, z2, w2, v2, S2, li);
                 });
                 cs[GCAR * kWave] = ag;
-                cs[DACC * kWave] = dAc;
+                cs[DACC * kWave] = dA0 + dA1;
             }
             S1 = ls_rows_sum<RPS>(S1);
             S2 = ls_rows_sum<RPS>(S2);
@@ -640,6 +676,15 @@ __global__ void __launch_bounds__(256) ssm_ls_bwd_kernel(const vivim_ssm_bwd_par
             p_du = duv; p_dd = ddv; p_chu = chu; p_t = t; p_st = st;
         }
         // ---- dB / dC of the tile: this row's channels are summed; add the rows and waves of the workgroup ----
+        // Both barriers sit around the slot writes: the first says "everybody is done reading the previous tile's slots and
+        // this tile's staged rows", the second "slots and the next tile's rows are written".  Back to back, the second
+        // finds the waves already aligned; spaced (one before, one after the reduction) they cost two synchronisations.
+        lds_barrier();
+        if (stage_next && tid < PT) {
+            *reinterpret_cast<u32x4*>(stage + tid * 16) = sb;
+            *reinterpret_cast<u32x4*>(stage + (PT + tid) * 16) = sc;
+        }
+        staged = stage_next;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             *reinterpret_cast<float4*>(slot + q * 4) = float4{dBv[q * 4], dBv[q * 4 + 1], dBv[q * 4 + 2], dBv[q * 4 + 3]};
@@ -660,7 +705,6 @@ __global__ void __launch_bounds__(256) ssm_ls_bwd_kernel(const vivim_ssm_bwd_par
                 }
             }
         }
-        lds_barrier();
     }
     flush();
     // ---- per-channel sums ----
@@ -681,12 +725,14 @@ __global__ void __launch_bounds__(256) ssm_ls_bwd_kernel(const vivim_ssm_bwd_par
 // Backward, pre-pass of the token-axis split: per (batch, channel, segment >= 1, state)
 //   agg  = g at the segment's first token for zero inflow from the right
 //   dsum = sum over the segment of delta_{t+1}
-// Waves are independent (no LDS, no barrier).
+// ONE channel per row here (a wave = 4 / RPS channels): four times the waves of the main kernel for the same cut -- the
+// recurrence is all there is, so what has to be hidden is load latency -- and nothing carried per channel but three
+// registers.  The next tile's inputs are requested before the current tile is computed.  No LDS, no barrier.
 // =========================================================================================================================
 template <typename T, int NS, bool HAS_Z>
 __global__ void __launch_bounds__(256) ssm_ls_bwd_prepass_kernel(const vivim_ssm_bwd_params p, const LsSeg sg) {
     typedef LsGeom<NS> G;
-    constexpr int RPS = G::RPS, CPW = G::CPW, CPR = kLsCPR;
+    constexpr int RPS = G::RPS, SPW = G::SPW;
     const vivim_ssm_fwd_params& f = p.f;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), W = blockDim.x >> 6;
@@ -696,83 +742,73 @@ __global__ void __launch_bounds__(256) ssm_ls_bwd_prepass_kernel(const vivim_ssm
     const int tk = ((li & 1) << 3) | ((li & 2) << 1) | ((li & 4) >> 1) | ((li & 8) >> 3);
     const int b = blockIdx.y, seg = blockIdx.z + 1;           // segment 0 has no left neighbour to feed
     const int L = f.seqlen, cpg = f.dim / f.n_groups;
-    const int cpb = W * CPW;
+    const int cpb = W * SPW;                                  // channels per workgroup
     const int bpg = (cpg + cpb - 1) / cpb;
     const int g = blockIdx.x / bpg;
     const int d_end = (g + 1) * cpg;
-    const int dwave = g * cpg + (blockIdx.x - g * bpg) * cpb + wave * CPW;
-    const int rowch = sw * CPR;
+    const int dwave = g * cpg + (blockIdx.x - g * bpg) * cpb + wave * SPW;    // first channel of this wave (uniform)
     if (dwave >= d_end) return;                               // whole waves only
+    const int d = dwave + sw;                                 // this row's channel
+    const bool cv = d < d_end;
+    const int dc = cv ? d : d_end - 1;
     const int ntiles = (L + kLsT - 1) / kLsT;
     const int nck = (ntiles + RPS - 1) / RPS;
     const int blk_lo = seg * sg.seg_blocks, blk_hi = min(nck, blk_lo + sg.seg_blocks);
     const int tile_lo = blk_lo * RPS, tile_hi = min(ntiles, blk_hi * RPS);
-    const int t_next = blk_hi * G::CK;
-    const float* __restrict__ Ap = static_cast<const float*>(f.A);
-    const float* __restrict__ biasp = static_cast<const float*>(f.delta_bias);
+    const int t_first = blk_lo * G::CK, t_next = blk_hi * G::CK;
     typedef vivim_ssm_bwd_params BP;
-    LsTensor<T> tdl, tdo, tz;
-    tdl.init(LS_OFF(BP, f.delta), LS_OFF(BP, f.delta_batch_stride), b, f.delta_d_stride, rowch);
-    tdo.init(LS_OFF(BP, dout), LS_OFF(BP, dout_batch_stride), b, p.dout_d_stride, rowch);
-    if (HAS_Z) tz.init(LS_OFF(BP, f.z), LS_OFF(BP, f.z_batch_stride), b, f.z_d_stride, rowch);
+    LsTensorR<T> tdl, tdo, tz;
+    tdl.init(f.delta, b * f.delta_batch_stride, f.delta_d_stride, sw);
+    tdo.init(p.dout, b * p.dout_batch_stride, p.dout_d_stride, sw);
+    if (HAS_Z) tz.init(f.z, b * f.z_batch_stride, f.z_d_stride, sw);
     LsRow<T> rC;
     rC.init(LS_OFF(BP, f.C), LS_OFF(BP, f.C_batch_stride), b, g, f.C_dstate_stride, n);
+    const float A2 = static_cast<const float*>(f.A)[dc * f.A_d_stride + n * f.A_dstate_stride] * kLog2e;
+    const float bias = f.delta_bias ? static_cast<const float*>(f.delta_bias)[dc] : 0.0f;
+    const bool softplus = ls_own((int)f.delta_softplus) != 0, bc_vec = ls_own(sg.bc_vec) != 0;
+    const int chu = min(dwave, d_end - 1);
 
-    float A2[CPR], gk[CPR], ag[CPR], dsum[CPR];            // g_t of the last token done, and a_t g_t
-#pragma unroll
-    for (int c = 0; c < CPR; ++c) {
-        const int dc = min(dwave + rowch + c, d_end - 1);
-        A2[c] = Ap[dc * f.A_d_stride + n * f.A_dstate_stride] * kLog2e;
-        gk[c] = 0.0f; ag[c] = 0.0f; dsum[c] = 0.0f;
-    }
-    int tokv = dwave;
+    float gg = 0.0f, ag = 0.0f, dsum = 0.0f;                  // g_t of the last token done, a_t g_t, sum of delta
+    // raw inputs of a tile (lanes that are off hold an arbitrary valid element: the consumer applies `ok`)
+    float n_raw, n_dy, n_z = 0.0f;
+    auto fetch = [&](int tile) __attribute__((always_inline)) {
+        const int t = tile * kLsT + tk;
+        const bool ok = cv && t < L && tile >= tile_lo;
+        n_raw = tdl.ld_raw(chu, t, ok);
+        n_dy = tdo.ld_raw(chu, t, ok);
+        if (HAS_Z) n_z = tz.ld_raw(chu, t, ok);
+    };
+    fetch(tile_hi - 1);
+#pragma unroll 1
     for (int tile = tile_hi - 1; tile >= tile_lo; --tile) {
         const int t0 = tile * kLsT;
         const int t = t0 + tk;
-        const bool tv = t < L;
+        const bool ok = cv && t < L;
         float Cv[16];
-        rC.load16(ls_fresh_kargs(), t0, L, sg.bc_vec && t0 + kLsT <= L, Cv);
-#pragma unroll
-        for (int c = 0; c < CPR; ++c) {
-            const int dw = ls_fresh_uniform(tokv);
-            const int d = dw + rowch + c;
-            const bool cv = d < d_end;
-            const int dc = cv ? d : d_end - 1;
-            const int chu = min(dw + c, d_end - 1);
-            const bool ok = cv && tv;
-            const ls_kargs q = ls_fresh_kargs();
-            const float raw = tdl.ld(q, chu, t, ok) + (biasp ? biasp[dc] : 0.0f);
-            float dy = tdo.ld(q, chu, t, ok);
-            if (HAS_Z) {
-                const float zf = tz.ld(q, chu, t, ok);
-                dy *= zf * sigmoidf_fast(zf);
-            }
-            float dl = ok ? (f.delta_softplus ? softplus_ref(raw) : raw) : 0.0f;
-            dsum[c] += (t == blk_lo * G::CK) ? 0.0f : dl;    // sum of delta over the segment minus its first token's
-            ls_settle(dl, dy);
-            float gg = gk[c], aa = ag[c];
-            sfor_down<16>([&](auto kc) {
-                constexpr int k = decltype(kc)::value;
-                gg = tok_fma<k>(aa, dy, Cv[k]);
-                aa = gg * fast_exp2(tok<k>(dl) * A2[c]);
-            });
-            gk[c] = gg; ag[c] = aa;
-            ls_tie(tokv, aa);
-        }
+        rC.load16(ls_fresh_kargs(), t0, L, bc_vec && t0 + kLsT <= L, Cv);
+        float raw = ok ? n_raw + bias : 0.0f, dy = ok ? n_dy : 0.0f, zf = ok ? n_z : 0.0f;
+        asm volatile("" : "+v"(raw), "+v"(dy), "+v"(zf));     // used here: before the next tile's loads are issued
+        fetch(tile - 1);
+        if (HAS_Z) dy *= zf * sigmoidf_fast(zf);
+        float dl = ok ? (softplus ? softplus_ref(raw) : raw) : 0.0f;
+        dsum += (t == t_first) ? 0.0f : dl;                   // sum of delta over the segment minus its first token's
+        ls_settle(dl, dy);
+        ls_arrive(Cv);
+        sfor_down<16>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            gg = tok_fma<k>(ag, dy, Cv[k]);
+            ag = gg * fast_exp2(tok<k>(dl) * A2);
+        });
     }
-#pragma unroll
-    for (int c = 0; c < CPR; ++c) {
-        const int d = dwave + rowch + c;
-        if (d >= d_end) continue;
-        sg.agg[(((int64_t)b * f.dim + d) * sg.S + seg) * NS + n] = gk[c];
-        float dl_nx = 0.0f;
-        if (t_next < L) {
-            const float raw = tdl.ld(ls_fresh_kargs(), min(dwave + c, d_end - 1), t_next, true) + (biasp ? biasp[d] : 0.0f);
-            dl_nx = f.delta_softplus ? softplus_ref(raw) : raw;
-        }
-        const float tot = ls_row_total(dsum[c]) + dl_nx;
-        if (li == 0 && rs == 0) sg.dsum[((int64_t)b * f.dim + d) * sg.S + seg] = tot;
+    if (!cv) return;                                          // uniform per row; the DPP sums below stay inside a row
+    sg.agg[(((int64_t)b * f.dim + d) * sg.S + seg) * NS + n] = gg;
+    float dl_nx = 0.0f;
+    if (t_next < L) {
+        const float raw = tdl.ld(chu, t_next, true) + bias;
+        dl_nx = softplus ? softplus_ref(raw) : raw;
     }
+    const float tot = ls_row_total(dsum) + dl_nx;
+    if (li == 0 && rs == 0) sg.dsum[((int64_t)b * f.dim + d) * sg.S + seg] = tot;
 }
 
 // gin[s-1] = exp2(A2 * dsum[s]) * gin[s] + agg[s], right to left (reverse == true), or
@@ -815,12 +851,16 @@ __global__ void __launch_bounds__(256) ssm_ls_carry_kernel(const float* __restri
 }
 
 // =========================================================================================================================
-// Forward: PASS 1 (end state of a segment for zero inflow, sum of delta) and PASS 2 (outputs and checkpoints)
+// Forward: PASS 1 (end state of a segment for zero inflow, sum of delta) and PASS 2 (outputs and checkpoints).
+// One loop over (tile, channel) steps like the backward: the running state of the row's kLsCPR channels lives in
+// wave-private LDS (one float per lane and channel), a step's inputs are requested one step ahead, its outputs are stored at
+// the start of the next step.  No barrier: waves are independent.
 // =========================================================================================================================
 template <typename T, int NS, int PASS, bool HAS_Z>
 __global__ void __launch_bounds__(256) ssm_ls_fwd_kernel(const vivim_ssm_fwd_params p, const LsSeg sg) {
     typedef LsGeom<NS> G;
     constexpr int RPS = G::RPS, CPW = G::CPW, CPR = kLsCPR;
+    __shared__ float lds_state[4 * CPR * 2 * kWave];          // [wave][channel][h | dsum][lane]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), W = blockDim.x >> 6;
     const int row = lane >> 4, li = lane & 15;
@@ -828,12 +868,12 @@ __global__ void __launch_bounds__(256) ssm_ls_fwd_kernel(const vivim_ssm_fwd_par
     const int n = rs * 16 + li;
     const int tk = ((li & 1) << 3) | ((li & 2) << 1) | ((li & 4) >> 1) | ((li & 8) >> 3);
     const int b = blockIdx.y, seg = blockIdx.z;
-    const int L = p.seqlen, cpg = p.dim / p.n_groups;
+    const int L = ls_own(p.seqlen), cpg = p.dim / p.n_groups;
     const int cpb = W * CPW;
     const int bpg = (cpg + cpb - 1) / cpb;
     const int g = blockIdx.x / bpg;
-    const int d_end = (g + 1) * cpg;
-    const int dwave = g * cpg + (blockIdx.x - g * bpg) * cpb + wave * CPW;
+    const int d_end = ls_own((g + 1) * cpg);
+    const int dwave = ls_own(g * cpg + (blockIdx.x - g * bpg) * cpb + wave * CPW);
     const int rowch = sw * CPR;
     if (dwave >= d_end) return;
     const int ntiles = (L + kLsT - 1) / kLsT;
@@ -841,13 +881,11 @@ __global__ void __launch_bounds__(256) ssm_ls_fwd_kernel(const vivim_ssm_fwd_par
     const int blk_lo = seg * sg.seg_blocks, blk_hi = min(nck, blk_lo + sg.seg_blocks);
     const int tile_lo = blk_lo * RPS, tile_hi = min(ntiles, blk_hi * RPS);
     if (PASS == 1 && seg == sg.S - 1) return;                 // the last segment feeds nobody
-    const float* __restrict__ Ap = static_cast<const float*>(p.A);
-    const float* __restrict__ Dp = static_cast<const float*>(p.D);
-    const float* __restrict__ biasp = static_cast<const float*>(p.delta_bias);
     typedef vivim_ssm_fwd_params FP;
-    LsTensor<T> tu, tdl, tz, to, toz;
-    tu.init(LS_OFF(FP, u), LS_OFF(FP, u_batch_stride), b, p.u_d_stride, rowch);
-    tdl.init(LS_OFF(FP, delta), LS_OFF(FP, delta_batch_stride), b, p.delta_d_stride, rowch);
+    LsTensorR<T> tu, tdl;                                     // loaded first in every step: resident
+    LsTensor<T> tz, to, toz;
+    tu.init(p.u, b * p.u_batch_stride, p.u_d_stride, rowch);
+    tdl.init(p.delta, b * p.delta_batch_stride, p.delta_d_stride, rowch);
     if (PASS == 2) {
         to.init(LS_OFF(FP, out), LS_OFF(FP, out_batch_stride), b, p.out_d_stride, rowch);
         if (HAS_Z) {
@@ -860,83 +898,110 @@ __global__ void __launch_bounds__(256) ssm_ls_fwd_kernel(const vivim_ssm_fwd_par
     LsRow<T> rB, rC;
     rB.init(LS_OFF(FP, B), LS_OFF(FP, B_batch_stride), b, g, p.B_dstate_stride, n);
     rC.init(LS_OFF(FP, C), LS_OFF(FP, C_batch_stride), b, g, p.C_dstate_stride, n);
+    const bool softplus = ls_own((int)p.delta_softplus) != 0, bc_vec = ls_own(sg.bc_vec) != 0;
+    float* cstate = lds_state + wave * (CPR * 2 * kWave) + lane;
+    static_assert(CPR == 4, "the per-channel registers are selected by hand");
 
-    float A2[CPR], h[CPR], dsum[CPR];
+    float A2r[CPR], Dr[CPR], biasr[CPR];
 #pragma unroll
     for (int c = 0; c < CPR; ++c) {
         const int d = dwave + rowch + c;
         const bool cv = d < d_end;
         const int dc = cv ? d : d_end - 1;
-        A2[c] = Ap[dc * p.A_d_stride + n * p.A_dstate_stride] * kLog2e;
-        h[c] = (PASS == 2 && sg.S > 1 && cv) ? sg.gin[(((int64_t)b * p.dim + dc) * sg.S + seg) * NS + n] : 0.0f;
-        dsum[c] = 0.0f;
+        A2r[c] = static_cast<const float*>(p.A)[dc * p.A_d_stride + n * p.A_dstate_stride] * kLog2e;
+        Dr[c] = p.D ? static_cast<const float*>(p.D)[dc] : 0.0f;
+        biasr[c] = p.delta_bias ? static_cast<const float*>(p.delta_bias)[dc] : 0.0f;
+        cstate[(c * 2 + 0) * kWave] = (PASS == 2 && sg.S > 1 && cv) ? sg.gin[(((int64_t)b * p.dim + dc) * sg.S + seg) * NS + n] : 0.0f;
+        cstate[(c * 2 + 1) * kWave] = 0.0f;
     }
-    int tokv = dwave;
+    float n_u, n_raw, n_z = 0.0f;
+    auto fetch = [&](int tile, int c) __attribute__((always_inline)) {
+        const int t = tile * kLsT + tk;
+        const bool ok = dwave + rowch + c < d_end && t < L && tile < tile_hi;
+        const int chu = min(dwave + c, d_end - 1);
+        n_u = tu.ld_raw(chu, t, ok);
+        n_raw = tdl.ld_raw(chu, t, ok);
+        if (PASS == 2 && HAS_Z) n_z = tz.ld_raw(ls_fresh_kargs(), chu, t, ok);
+    };
+    // outputs of the previous step, stored at the start of the next one (see the backward kernel)
+    float p_o = 0.0f, p_oz = 0.0f, p_h = 0.0f;
+    int p_chu = min(dwave, d_end - 1), p_t = 0, p_ck = 0;
+    bool p_st = false, p_ckst = false;
+    auto flush = [&]() __attribute__((always_inline)) {
+        if (PASS == 2) {
+            const ls_kargs qs = ls_fresh_kargs();
+            to.st(qs, p_chu, p_t, p_st, p_o);
+            if (HAS_Z) toz.st(qs, p_chu, p_t, p_st, p_oz);
+            tx.st(qs, p_chu, p_ck * NS + n, p_ckst, p_h);
+        }
+    };
+    float Bv[16], Cv[16];
+    fetch(tile_lo, 0);
+#pragma unroll 1
     for (int tile = tile_lo; tile < tile_hi; ++tile) {
         const int t0 = tile * kLsT;
         const int t = t0 + tk;
         const bool tv = t < L;
-        float Bv[16], Cv[16];
         {
-            const bool vec = sg.bc_vec && t0 + kLsT <= L;
+            const bool vec = bc_vec && t0 + kLsT <= L;
             const ls_kargs q = ls_fresh_kargs();
             rB.load16(q, t0, L, vec, Bv);
             if (PASS == 2) rC.load16(q, t0, L, vec, Cv);
         }
+        ls_arrive(Bv);
+        if (PASS == 2) ls_arrive(Cv);
         const bool ck_row = PASS == 2 && (((tile + 1) % RPS) == 0 || tile == ntiles - 1);   // a checkpoint row ends here
-#pragma unroll
+#pragma unroll 1
         for (int c = 0; c < CPR; ++c) {
-            const int dw = ls_fresh_uniform(tokv);
-            const int d = dw + rowch + c;
+            const int d = dwave + rowch + c;
             const bool cv = d < d_end;
-            const int dc = cv ? d : d_end - 1;
-            const int chu = min(dw + c, d_end - 1);
+            const int chu = min(dwave + c, d_end - 1);
             const bool ok = cv && tv;
-            const bool st = ok && rs == 0;
-            const ls_kargs q = ls_fresh_kargs();
-            const float uu = tu.ld(q, chu, t, ok);
-            const float raw = tdl.ld(q, chu, t, ok) + (biasp ? biasp[dc] : 0.0f);
-            float zf = 0.0f;
-            if (PASS == 2 && HAS_Z) zf = tz.ld(q, chu, t, ok);
-            float dl = ok ? (p.delta_softplus ? softplus_ref(raw) : raw) : 0.0f;           // fwd_kernel.cuh:153-156
+            float uu = ok ? n_u : 0.0f, raw = ok ? n_raw : 0.0f, zf = ok ? n_z : 0.0f;
+            asm volatile("" : "+v"(uu), "+v"(raw), "+v"(zf)); // used here: before the next step's loads are issued
+            flush();
+            fetch(c + 1 < CPR ? tile : tile + 1, c + 1 < CPR ? c + 1 : 0);
+            const float A2 = c == 0 ? A2r[0] : c == 1 ? A2r[1] : c == 2 ? A2r[2] : A2r[3];
+            raw += c == 0 ? biasr[0] : c == 1 ? biasr[1] : c == 2 ? biasr[2] : biasr[3];
+            float dl = ok ? (softplus ? softplus_ref(raw) : raw) : 0.0f;                   // fwd_kernel.cuh:153-156
             float w = dl * uu;
-            dsum[c] += dl;
+            float* cs = cstate + c * 2 * kWave;
+            if (PASS == 1) cs[kWave] += dl;
             ls_settle(dl, w);
-            float hh = h[c];
+            float hh = cs[0];
             if (PASS == 1) {
                 sfor<0, 16>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
-                    const float a = fast_exp2(tok<k>(dl) * A2[c]);                        // fwd_kernel.cuh:216
+                    const float a = fast_exp2(tok<k>(dl) * A2);                            // fwd_kernel.cuh:216
                     hh = tok_fma<k>(a * hh, w, Bv[k]);
                 });
-                h[c] = hh;
-                ls_tie(tokv, hh);
+                cs[0] = hh;
             } else {
                 float s[16], z[8], ww[4], v[2], y;
                 sfor<0, 16>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
-                    const float a = fast_exp2(tok<k>(dl) * A2[c]);
+                    const float a = fast_exp2(tok<k>(dl) * A2);
                     hh = tok_fma<k>(a * hh, w, Bv[k]);
                     s[k] = hh * Cv[k];                                                     // fwd_kernel.cuh:256-265
                     ls_reduce_up<k>(s, z, ww, v, y, li);
                 });
-                h[c] = hh;
+                cs[0] = hh;
                 y = ls_rows_sum<RPS>(y);
-                const float o = fmaf(Dp ? Dp[dc] : 0.0f, uu, y);
-                to.st(q, chu, t, st, o);
-                if (HAS_Z) toz.st(q, chu, t, st, o * zf * sigmoidf_fast(zf));                 // fwd_kernel.cuh:280-298
-                if (ck_row) tx.st(q, chu, (tile / RPS) * NS + n, cv, hh);
-                ls_tie(tokv, hh + y);
+                const float Dv = c == 0 ? Dr[0] : c == 1 ? Dr[1] : c == 2 ? Dr[2] : Dr[3];
+                const float o = fmaf(Dv, uu, y);
+                p_o = o;
+                if (HAS_Z) p_oz = o * zf * sigmoidf_fast(zf);                              // fwd_kernel.cuh:280-298
+                p_h = hh; p_chu = chu; p_t = t; p_st = ok && rs == 0; p_ck = tile / RPS; p_ckst = ck_row && cv;
             }
         }
     }
+    flush();
     if (PASS == 1) {
-#pragma unroll
         for (int c = 0; c < CPR; ++c) {
             const int d = dwave + rowch + c;
+            const float tot = ls_row_total(cstate[(c * 2 + 1) * kWave]);
             if (d >= d_end) continue;
-            sg.agg[(((int64_t)b * p.dim + d) * sg.S + seg) * NS + n] = h[c];
-            const float tot = ls_row_total(dsum[c]);
+            sg.agg[(((int64_t)b * p.dim + d) * sg.S + seg) * NS + n] = cstate[(c * 2 + 0) * kWave];
             if (li == 0 && rs == 0) sg.dsum[((int64_t)b * p.dim + d) * sg.S + seg] = tot;
         }
     }
@@ -958,9 +1023,21 @@ static int ls_cu_count() {
 
 // Shape-only test (the checkpoint layout of `x` follows from it, so forward and backward must agree without looking at
 // pointers): variable B / C and a state count that fills whole rows.
+// ... whose (channel, token) byte offsets inside one batch element fit the 32-bit offsets of the buffer accesses (sizes
+// and strides only: the query must not depend on pointers).
+static bool ls_span_ok(int64_t rows, int64_t row_stride, int64_t len, int esize) {
+    return row_stride >= 0 && ((rows - 1) * row_stride + len) * esize < (int64_t)0xffff0000;
+}
 bool ls_shape_ok(const vivim_ssm_fwd_params& f) {
-    return f.is_variable_B && f.is_variable_C && (f.dstate == 16 || f.dstate == 32 || f.dstate == 64) &&
-           f.dim % f.n_groups == 0;
+    if (!(f.is_variable_B && f.is_variable_C && (f.dstate == 16 || f.dstate == 32 || f.dstate == 64) && f.dim % f.n_groups == 0))
+        return false;
+    const int es = f.itype == VIVIM_F32 ? 4 : 2;
+    if (f.dim > 65535 || !ls_span_ok(f.dim, f.u_d_stride, f.seqlen, es) || !ls_span_ok(f.dim, f.delta_d_stride, f.seqlen, es) ||
+        !ls_span_ok(f.dstate, f.B_dstate_stride, f.seqlen, es) || !ls_span_ok(f.dstate, f.C_dstate_stride, f.seqlen, es) ||
+        !ls_span_ok(f.dim, (int64_t)((f.seqlen + 15) / 16) * f.dstate, 0, 4))
+        return false;
+    if (f.z && (!ls_span_ok(f.dim, f.z_d_stride, f.seqlen, es))) return false;
+    return true;
 }
 int ls_ckpt_len(const vivim_ssm_fwd_params& f) { return 16 * (f.dstate / 16); }
 
@@ -989,16 +1066,57 @@ static void ls_segmentation(const vivim_ssm_fwd_params& f, int waves_per_seg, in
     S = (nck + seg_blocks - 1) / seg_blocks;
 }
 
-// resident waves per CU: the backward at 3 waves per SIMD (<= 168 VGPRs, 52.5 KB of LDS per 4-wave workgroup), the
-// forward / pre-pass kernels at 8 (<= 64 VGPRs) or 7
+// Resident workgroups per CU of the backward instantiation that `f` selects, from the occupancy query (registers and LDS
+// differ between instantiations: 2 or 3 waves per SIMD); cached.  A build host without a GPU answers 3.
+template <typename T, int NS, bool HAS_Z> static int ls_bwd_blocks_per_cu_of(int W, size_t smem) {
+    static int cache[5] = {0, 0, 0, 0, 0};                    // by W (1..4)
+    if (cache[W] == 0) {
+        int nb = 0;
+        if (smem > 65536)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ssm_ls_bwd_kernel<T, NS, HAS_Z>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ssm_ls_bwd_kernel<T, NS, HAS_Z>, W * kWave, smem) != hipSuccess || nb <= 0) {
+            (void)hipGetLastError();
+            nb = 3;
+        }
+        cache[W] = nb;
+    }
+    return cache[W];
+}
+static size_t ls_bwd_smem(int W, int NS) {
+    // per wave: 8 KB of dB / dC slots + the channels' state (4 floats per lane and channel; dstate 32 / 64: + the rebuilt
+    // states at the inner tile boundaries of a checkpoint block) + the D / bias table: 50.1 KB for 4 waves at dstate 16
+    const int RPS = NS / 16, SPW = 4 / RPS;
+    return ((size_t)W * SPW * 2 * NS * 16 + (size_t)W * kLsCPR * (4 + RPS - 1) * kWave + (size_t)W * kLsCPR * 8) * sizeof(float) +
+           (size_t)2 * NS * 16 * 4;                            // + the staged B / C rows of one tile (sized for fp32)
+}
+template <typename T> static int ls_bwd_blocks_per_cu_t(const vivim_ssm_fwd_params& f, int W) {
+    const size_t smem = ls_bwd_smem(W, f.dstate);
+    const bool z = f.z != nullptr;
+    switch (f.dstate) {
+        case 16: return z ? ls_bwd_blocks_per_cu_of<T, 16, true>(W, smem) : ls_bwd_blocks_per_cu_of<T, 16, false>(W, smem);
+        case 32: return z ? ls_bwd_blocks_per_cu_of<T, 32, true>(W, smem) : ls_bwd_blocks_per_cu_of<T, 32, false>(W, smem);
+        case 64: return z ? ls_bwd_blocks_per_cu_of<T, 64, true>(W, smem) : ls_bwd_blocks_per_cu_of<T, 64, false>(W, smem);
+    }
+    return 3;
+}
+static int ls_bwd_blocks_per_cu(const vivim_ssm_fwd_params& f, int W) {
+    switch (f.itype) {
+        case VIVIM_F32: return ls_bwd_blocks_per_cu_t<float>(f, W);
+        case VIVIM_F16: return ls_bwd_blocks_per_cu_t<f16_t>(f, W);
+        case VIVIM_BF16: return ls_bwd_blocks_per_cu_t<bf16_t>(f, W);
+    }
+    return 3;
+}
+
 static void ls_bwd_plan(const vivim_ssm_fwd_params& f, int& W, int& S, int& seg_blocks) {
     W = ls_bwd_waves(f);
     const int cpw = (4 / (f.dstate / 16)) * kLsCPR;
     const int cpg = f.dim / f.n_groups;
     const int bpg = (cpg + W * cpw - 1) / (W * cpw);
     const int waves_per_seg = bpg * W * f.n_groups * f.batch;
-    ls_segmentation(f, waves_per_seg, ls_cu_count() * 12, 4, S, seg_blocks);
+    ls_segmentation(f, waves_per_seg, ls_cu_count() * ls_bwd_blocks_per_cu(f, W) * W, 4, S, seg_blocks);
 }
+// the forward / pre-pass kernels: 7 - 8 waves per SIMD (<= 72 VGPRs), no LDS
 static void ls_fwd_plan(const vivim_ssm_fwd_params& f, int& S, int& seg_blocks) {
     const int cpw = (4 / (f.dstate / 16)) * kLsCPR;
     const int cpg = f.dim / f.n_groups;
@@ -1042,7 +1160,7 @@ static bool launch_ls_bwd(const vivim_ssm_bwd_params& p, hipStream_t stream) {
     ls_bwd_plan(f, W, S, seg_blocks);
     const int ck = G::CK;
     const int nck = (f.seqlen + ck - 1) / ck;
-    LsSeg sg = {1, nck, nullptr, nullptr, nullptr, ls_bc_vec(f) ? 1 : 0};
+    LsSeg sg = {1, nck, nullptr, nullptr, nullptr, ls_bc_vec(f) ? 1 : 0, getenv("VIVIM_LS_DBG") ? atoi(getenv("VIVIM_LS_DBG")) : 0};
     const size_t need = ls_bwd_workspace_bytes(f);
     if (need && p.workspace && (size_t)p.workspace_bytes >= need) {
         sg.S = S;
@@ -1052,8 +1170,8 @@ static bool launch_ls_bwd(const vivim_ssm_bwd_params& p, hipStream_t stream) {
     const int cpg = f.dim / f.n_groups;
     const int bpg = (cpg + W * G::CPW - 1) / (W * G::CPW);
     if (sg.S > 1) {
-        const int PW = 4;                                     // independent waves per pre-pass workgroup
-        const int pbpg = (cpg + PW * G::CPW - 1) / (PW * G::CPW);
+        const int PW = 4;                                     // independent waves per pre-pass workgroup, one channel per row
+        const int pbpg = (cpg + PW * G::SPW - 1) / (PW * G::SPW);
         const dim3 gpre(pbpg * f.n_groups, f.batch, sg.S - 1);
         if (f.z) hipLaunchKernelGGL((ssm_ls_bwd_prepass_kernel<T, NS, true>), gpre, dim3(PW * kWave), 0, stream, p, sg);
         else     hipLaunchKernelGGL((ssm_ls_bwd_prepass_kernel<T, NS, false>), gpre, dim3(PW * kWave), 0, stream, p, sg);
@@ -1062,9 +1180,7 @@ static bool launch_ls_bwd(const vivim_ssm_bwd_params& p, hipStream_t stream) {
                            static_cast<const float*>(f.A), f.A_d_stride, f.A_dstate_stride, f.batch, f.dim, f.dstate, sg);
     }
     const dim3 grid(bpg * f.n_groups, f.batch, sg.S);
-    // per wave: 8 KB of dB / dC slots + the channels' state (5 floats per lane and channel; dstate 32 / 64: + the rebuilt
-    // states at the inner tile boundaries of a checkpoint block) + the D / bias table: 52.1 KB for 4 waves at dstate 16
-    const size_t smem = ((size_t)W * G::SPW * 2 * NS * 16 + (size_t)W * kLsCPR * (5 + G::RPS - 1) * kWave + (size_t)W * kLsCPR * 8) * sizeof(float);
+    const size_t smem = ls_bwd_smem(W, NS);
     auto launch = [&](auto kernel) {
         if (smem > 65536)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1081,7 +1197,7 @@ static bool launch_ls_fwd(const vivim_ssm_fwd_params& p, hipStream_t stream) {
     int S, seg_blocks;
     ls_fwd_plan(p, S, seg_blocks);
     const int nck = (p.seqlen + G::CK - 1) / G::CK;
-    LsSeg sg = {1, nck, nullptr, nullptr, nullptr, ls_bc_vec(p) ? 1 : 0};
+    LsSeg sg = {1, nck, nullptr, nullptr, nullptr, ls_bc_vec(p) ? 1 : 0, 0};
     const size_t need = ls_fwd_workspace_bytes(p);
     if (need && p.workspace && (size_t)p.workspace_bytes >= need) {
         sg.S = S;
@@ -1122,6 +1238,16 @@ template <typename T> static bool ls_fwd_by_n(const vivim_ssm_fwd_params& p, hip
 
 bool try_ls_bwd(const vivim_ssm_bwd_params& p, hipStream_t stream) {
     if (!ls_shape_ok(p.f) || p.f.x == nullptr) return false;
+    {   // the tensors only the backward sees
+        const vivim_ssm_fwd_params& f = p.f;
+        const int es = f.itype == VIVIM_F32 ? 4 : 2;
+        if (!ls_span_ok(f.dim, p.dout_d_stride, f.seqlen, es) || !ls_span_ok(f.dim, p.du_d_stride, f.seqlen, es) ||
+            !ls_span_ok(f.dim, p.ddelta_d_stride, f.seqlen, es))
+            return false;
+        if (f.z && (!ls_span_ok(f.dim, f.out_d_stride, f.seqlen, es) || !ls_span_ok(f.dim, p.dz_d_stride, f.seqlen, es) ||
+                    (f.out_z && !ls_span_ok(f.dim, f.out_z_d_stride, f.seqlen, es))))
+            return false;
+    }
     switch (p.f.itype) {
         case VIVIM_F32: return ls_bwd_by_n<float>(p, stream);
         case VIVIM_F16: return ls_bwd_by_n<f16_t>(p, stream);
@@ -1131,6 +1257,11 @@ bool try_ls_bwd(const vivim_ssm_bwd_params& p, hipStream_t stream) {
 }
 bool try_ls_fwd(const vivim_ssm_fwd_params& p, hipStream_t stream) {
     if (!ls_shape_ok(p)) return false;
+    {
+        const int es = p.itype == VIVIM_F32 ? 4 : 2;
+        if (!ls_span_ok(p.dim, p.out_d_stride, p.seqlen, es) || (p.z && !ls_span_ok(p.dim, p.out_z_d_stride, p.seqlen, es)))
+            return false;           // the caller reports "not implemented" (out / out_z normally inherit delta's / z's strides,
+    }                               // which ls_shape_ok has already accepted)
     switch (p.itype) {
         case VIVIM_F32: return ls_fwd_by_n<float>(p, stream);
         case VIVIM_F16: return ls_fwd_by_n<f16_t>(p, stream);
