@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--d-state", type=int, default=16)
     ap.add_argument("--expand", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-by-config", action="store_true", help="skip the per-config kernel timings after the timed region")
     ap.add_argument("--stock-backbone-dwconv", action="store_true",
                     help="leave the SegFormer blocks stock: Mix-FFN depthwise convs on MIOpen instead of csrc/dwconv.hip, "
                          "transformers' own DropPath")
@@ -132,21 +133,70 @@ def measured_copy_ceiling(dev, nbytes=1 << 30, iters=10):
     return round(2 * nbytes * iters / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
 
 
-def pmc_traffic(entry_point):
-    """HBM bytes per launch of a hot-path entry point as measured by rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over
-    this very command (tools/pmc_bench_traffic.py; bench.py cannot run the profiler on itself): the newest committed
-    profiles/r*_bench_pmc_traffic.json, or None."""
+def pmc_record(entry_point):
+    """What rocprofv3 --pmc passes over this very command measured per launch of a hot-path entry point (bench.py cannot run
+    the profiler on itself): HBM bytes (FETCH_SIZE / WRITE_SIZE) and VALU wave-instructions (SQ_INSTS_VALU), from the newest
+    committed profiles/r*_bench_pmc_traffic.json (tools/pmc_bench_traffic.py).  The record carries a hash of the kernel
+    sources it was taken on: a record of other kernels is reported as stale, not as a measurement.
+    -> (hbm_bytes | None, valu_insts | None, source file | None, stale: bool)"""
     import glob
     import re
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc_traffic.json")),
                    key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])     # r01_v10 after r01_v9
     if not files:
-        return None, None
+        return None, None, None, False
     try:
-        rec = json.load(open(files[-1]))["per_entry_point"][entry_point]
-        return int(rec["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
-    except (KeyError, ValueError, OSError):
-        return None, None
+        doc = json.load(open(files[-1]))
+        rec = doc["per_entry_point"][entry_point]
+        from pmc_bench_traffic import kernels_sha
+        stale = doc.get("kernels_sha") != kernels_sha()
+        return (int(rec["hbm_bytes_per_launch"]), rec.get("valu_wave_insts_per_launch"), os.path.relpath(files[-1], ROOT), stale)
+    except (KeyError, ValueError, OSError, ImportError):
+        return None, None, None, False
+
+
+VALU_PEAK_GINST = 1024 * 2.4 / 2      # wave-instructions per ns: 1024 SIMD-32 x 2.4 GHz, one wave64 instruction per 2 cycles
+
+
+def roofline_by_config(dev, iters=4):
+    """The scan kernels alone at the stage-0 shapes of BASELINE.json configs[1], [2] and [4] (the grouped v3 layout: three
+    directions side by side, dim = 3 * d_inner, n_groups = 3), a few launches each through the C ABI, HIP-event timed like the
+    timed region: configs[2] is BASELINE's HBM-bandwidth headline, configs[4] its wide-state stress.  Runs after the timed
+    region; rank 0 only."""
+    import selective_scan_cuda as ss
+    from vivim_amd import _lib
+    out = {}
+    for key, (B, nf, img, N, expand, dt) in {"cfg2": (3, 5, 256, 16, 2, torch.bfloat16), "cfg3": (8, 5, 512, 16, 2, torch.float32),
+                                             "cfg5": (1, 8, 256, 64, 4, torch.bfloat16)}.items():
+        G, D, L = 3, 64 * expand * 3, nf * (img // 4) ** 2
+        g = torch.Generator(device=dev).manual_seed(7)
+        mk = lambda *sh: torch.randn(*sh, device=dev, generator=g).to(dt)
+        u, z, dout = mk(B, D, L), mk(B, D, L), mk(B, D, L)
+        delta = (0.2 * torch.randn(B, D, L, device=dev, generator=g)).to(dt)
+        A = -torch.arange(1, N + 1, device=dev, dtype=torch.float32).repeat(D, 1)
+        Bm, Cm = mk(B, G, N, L), mk(B, G, N, L)
+        Dv, bias = torch.ones(D, device=dev), torch.full((D,), -4.0, device=dev)
+        res = ss.fwd(u, delta, A, Bm, Cm, Dv, z, bias, True)          # warm-up + the checkpoints the backward reads
+        dz = torch.empty_like(z)
+        ss.bwd(u, delta, A, Bm, Cm, Dv, z, bias, dout, res[1], res[0], dz, True, False)
+        _lib.profile_begin()
+        for _ in range(iters):
+            r = ss.fwd(u, delta, A, Bm, Cm, Dv, z, bias, True)
+            ss.bwd(u, delta, A, Bm, Cm, Dv, z, bias, dout, r[1], r[0], dz, True, False)
+        rec = _lib.profile_end()
+        e = {"shape": {"batch": B, "dim": D, "n_groups": G, "dstate": N, "seqlen": L, "dtype": str(dt).replace("torch.", "")},
+             "checkpoint_row_tokens": L // res[1].shape[2] if res[1].shape[2] else L}
+        for name in ("vivim_selective_scan_fwd", "vivim_selective_scan_bwd"):
+            rows = [x for x in rec if x[0] == name]
+            sec, nb = sum(x[2] for x in rows), sum(x[1] for x in rows)
+            e[name.replace("vivim_", "")] = {"avg_us": round(sec / len(rows) * 1e6, 1), "achieved_GBps": round(nb / sec / 1e9, 1),
+                                             "frac": round(nb / sec / 1e9 / HBM_PEAK_GBS, 4),
+                                             "state_updates_per_launch": B * D * L * N}
+        out[key] = e
+        del u, z, dout, delta, Bm, Cm, res, dz, r
+        torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -196,6 +246,12 @@ def main():
     records = _lib.profile_end()
     elapsed = dp.max_over_ranks(elapsed, dev)
     assert torch.isfinite(loss), "non-finite loss"
+    comm = {}
+    try:                                                       # every rank takes part; rank 0 reports
+        comm = dp.comm_probe(step_model, lambda: train_step(step_model, opt, clip, onehot, a.num_classes, amp),
+                             elapsed / a.steps * 1e3, dev)
+    except Exception as ex:
+        comm = {"error": repr(ex)[:200]}
 
     if rank == 0:
         frames = world * a.train_bs * a.clip_length * a.steps
@@ -208,7 +264,17 @@ def main():
         hot = [k for k in per if "selective_scan" in k or "causal_conv1d" in k]   # the north-star path's kernels
         dom = max(hot, key=lambda k: per[k][1])
         ach = per[dom][0] / per[dom][1] / 1e9
-        traffic, traffic_src = pmc_traffic(dom.replace("vivim_", ""))
+        traffic, valu_insts, traffic_src, stale = pmc_record(dom.replace("vivim_", ""))
+        avg_s = per[dom][1] / per[dom][2]
+        # the VALU co-limit: the scans carry N exp2 + ~20 N fp32 operations per token and channel; their issue rate against
+        # the chip's (one wave64 instruction per 2 cycles and SIMD) says how far the kernel is from its OTHER roof
+        co = None
+        if valu_insts and not stale:
+            co = {"kind": "valu", "wave_insts_per_launch": int(valu_insts),
+                  "achieved_Ginst_per_s": round(valu_insts / avg_s / 1e9, 1), "peak_Ginst_per_s": round(VALU_PEAK_GINST * 1e3, 1),
+                  "frac": round(valu_insts / avg_s / 1e9 / (VALU_PEAK_GINST * 1e3), 4),
+                  "note": "SQ_INSTS_VALU per launch (committed PMC pass) / live launch time; the larger of roofline.frac and "
+                          "this one names the bound"}
         kernels = {k.replace("vivim_", ""): {"launches": v[2], "total_ms": round(v[1] * 1e3, 3),
                                               "avg_us": round(v[1] / v[2] * 1e6, 2),
                                               "alg_GBps": round(v[0] / v[1] / 1e9, 1)} for k, v in per.items()}
@@ -227,14 +293,22 @@ def main():
                        "step_mode": mode},
             "roofline": {"bound": "hbm", "kernel": dom.replace("vivim_", ""), "achieved": round(ach, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-                         "traffic": traffic, "traffic_unit": "bytes per launch (PMC, separate passes)",
-                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(per[dom][0] / per[dom][2]),
+                         "traffic": None if stale else traffic, "traffic_unit": "bytes per launch (PMC, separate passes)",
+                         "traffic_source": traffic_src, "traffic_stale": bool(stale), "co_limit": co,
+                         "algorithmic_bytes_per_launch": int(per[dom][0] / per[dom][2]),
                          "launches": per[dom][2],
                          "avg_launch_us": round(per[dom][1] / per[dom][2] * 1e6, 2),
                          "measured_copy_GBps": measured_copy_ceiling(dev)},
             "kernels": kernels,
             "loss": round(float(loss), 5),
         }
+        if comm:
+            out["comm"] = comm                                 # allreduce_ms, overlap_frac, n_ranks_seen (N > 1)
+        if world == 1 and not a.no_by_config:
+            try:
+                out["roofline_by_config"] = roofline_by_config(dev)
+            except Exception as ex:                            # never lose the headline line to the extras
+                out["roofline_by_config"] = {"error": repr(ex)[:200]}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         sys.stdout.flush()

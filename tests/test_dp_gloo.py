@@ -44,6 +44,15 @@ def _worker(rank, world, port, out):
     loss = torch.nn.functional.mse_loss(ddp(x), y)
     loss.backward()
     dp.barrier()
+
+    def one_step():
+        ddp.zero_grad()
+        torch.nn.functional.mse_loss(ddp(x), y).backward()
+    probe = dp.comm_probe(ddp, one_step, sync_ms_per_step=5.0)          # what bench.py reports under torchrun
+    assert probe["n_ranks_seen"] == world and probe["allreduce_ms"] > 0 and 0.0 <= probe["overlap_frac"] <= 1.0
+    assert probe["allreduce_MB"] >= 0 and probe["ms_per_step_no_exchange"] > 0
+    ddp.zero_grad()
+    torch.nn.functional.mse_loss(ddp(x), y).backward()                  # all-reduced again after the unsynchronised steps
     t = dp.max_over_ranks(1.0 + rank)
     grads = torch.cat([p.grad.flatten() for p in model.parameters() if p.requires_grad])
     torch.save({"grads": grads, "x": x, "y": y, "t": t}, os.path.join(out, f"r{rank}.pt"))
@@ -72,3 +81,19 @@ def test_single_process_helpers_are_identity():
     from vivim_amd import dp
     m = torch.nn.Linear(2, 2)
     assert dp.wrap(m) is m and dp.max_over_ranks(3.5) == 3.5 and dp.shard_seed(1, 3) == 4
+
+
+def test_freeze_unused_on_the_real_parameter_list():
+    """The real Vivim (random-init SegFormer-b3 backbone, CPU, no forward): freeze_unused must freeze exactly the two
+    parameter groups the forward never reaches (modeling/vivim.py:211-212, 325) -- what DDP then reduces is every other
+    parameter.  (tests/test_gpu_model.py checks on the GPU that each of those does receive a gradient.)"""
+    sys.path.insert(0, ROOT)
+    from vivim_amd.train_step import build_model
+    model = build_model(3, "cpu")
+    frozen = sorted(n for n, p in model.named_parameters() if not p.requires_grad)
+    assert frozen, "nothing frozen"
+    assert all(n.startswith("decoder.classifier.") or ".layer_norm." in n and n.startswith("encoder.downsample_layers.")
+               for n in frozen), frozen
+    live = [n for n, p in model.named_parameters() if p.requires_grad]
+    assert not any(n.startswith("decoder.classifier.") for n in live)
+    assert len(live) > 500                                               # SegFormer-b3 + 8 Mamba layers + head

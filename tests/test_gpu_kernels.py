@@ -11,7 +11,7 @@ outer bounds the reference itself uses are rtol/atol 6e-4/2e-3 (fp32), 3e-3/5e-3
 import pytest
 import torch
 
-from conftest import DT, golden_names, load_golden, rel_err
+from conftest import CONV_CLOSE, DT, SCAN_CLOSE, check_close, golden_names, load_golden, rel_err
 from oracle import cpu_oracle
 
 pytestmark = pytest.mark.gpu
@@ -81,10 +81,10 @@ def test_conv_vs_oracle(dtype, width, seqlen, cuda, ops):
     for silu, bias in ((True, b), (False, None)):
         out = cc.causal_conv1d_fwd(x, w, bias, silu)
         ref = cpu_oracle.causal_conv1d_fwd(x, w, bias, silu)
-        assert rel_err(out.float(), _round(ref, dtype)) < _tol(dtype), (silu,)
+        check_close("conv_out", out, _round(ref, dtype), dtype, CONV_CLOSE, _tol(dtype))
         dx, dw, db = cc.causal_conv1d_bwd(x, w, bias, dout, None, silu)
         rdx, rdw, rdb = cpu_oracle.causal_conv1d_bwd(x, w, bias, dout, silu)
-        assert rel_err(dx.float(), _round(rdx, dtype)) < _tol(dtype)
+        check_close("conv_dx", dx, _round(rdx, dtype), dtype, CONV_CLOSE, _tol(dtype))
         assert rel_err(dw, rdw) < 1e-4
         if bias is not None:
             assert rel_err(db, rdb) < 1e-4
@@ -245,7 +245,10 @@ def _dz_from_saved_out(dout, out, z):
     return dout.float() * out.float() * sg * (1 + zf * (1 - sg))
 
 
-def _check_scan(t, ss, expect_fwd=None, expect_bwd=None, tol=None):
+def _check_scan(t, ss, expect_fwd=None, expect_bwd=None, tol=None, gtol=None):
+    """Forward and backward of one problem against the oracle (or the given expected tensors): norm-wise rel-err within
+    `tol` (outputs) / `gtol` (gradients), AND the reference's own elementwise rtol / atol (conftest.check_close) for out,
+    out_z, the last state, du, ddelta, dz -- the check that sees a single wrong token or channel."""
     dt = t["dtype"]
     tol = tol or _tol(dt)
     res = ss.fwd(t["u"], t["delta"], t["A"], t["B"], t["C"], t["D"], t["z"], t["delta_bias"], t["softplus"])
@@ -257,10 +260,10 @@ def _check_scan(t, ss, expect_fwd=None, expect_bwd=None, tol=None):
     else:
         r_out, r_out_z, r_last = expect_fwd
     if r_out is not None:
-        assert rel_err(out.float(), _round(r_out, dt)) < tol
+        check_close("out", out, _round(r_out, dt), dt, SCAN_CLOSE, tol)
     if out_z is not None:
-        assert rel_err(out_z.float(), _round(r_out_z, dt)) < tol
-    assert rel_err(x[:, :, -1, :], r_last) < max(tol, 1e-5)
+        check_close("out_z", out_z, _round(r_out_z, dt), dt, SCAN_CLOSE, tol)
+    check_close("last_state", x[:, :, -1, :], r_last, torch.float32, SCAN_CLOSE, max(tol, 1e-5))
     dz_buf = torch.empty_like(t["z"]) if t["z"] is not None else None
     grads = ss.bwd(t["u"], t["delta"], t["A"], t["B"], t["C"], t["D"], t["z"], t["delta_bias"], t["dout"], x,
                    out if t["z"] is not None else None, dz_buf, t["softplus"], False)
@@ -268,23 +271,30 @@ def _check_scan(t, ss, expect_fwd=None, expect_bwd=None, tol=None):
     r = expect_bwd or cpu_oracle.selective_scan_bwd(t["u"], t["delta"], t["A"], t["B"], t["C"], t["D"], t["z"],
                                                     t["delta_bias"], t["dout"], t["softplus"])
     lo = dt != torch.float32
-    gt = tol * (4 if lo else 5)       # low-precision grads are products of rounded inputs; fp32: 1e-4
-    assert rel_err(du.float(), _round(r["du"], dt)) < gt, "du"
-    assert rel_err(ddelta.float(), _round(r["ddelta"], dt)) < gt, "ddelta"
-    assert rel_err(dA, r["dA"]) < gt, "dA"
-    assert rel_err(dB.float(), _round(r["dB"], dB.dtype)) < gt, "dB"
-    assert rel_err(dC.float(), _round(r["dC"], dC.dtype)) < gt, "dC"
+    # 16-bit I/O: the per-token gradients are rounded once like the outputs and meet the same 1e-3 (measured 2e-5 ... 4e-4,
+    # profiles/r02_parity_relerr.log); fp32: 1e-4
+    gt = gtol or (tol if lo else tol * 5)
+    check_close("du", du, _round(r["du"], dt), dt, SCAN_CLOSE, gt)
+    check_close("ddelta", ddelta, _round(r["ddelta"], dt), dt, SCAN_CLOSE, gt)
+    # parameter gradients sum rounded 16-bit products over batch and tokens: norm-wise only there (the reference compares
+    # them at rtol 3e-2 / atol 0.25 in bf16, test_selective_scan.py:216-229)
+    pg = 4 * gt if lo else gt
+    if not lo:
+        check_close("dA", dA, r["dA"], torch.float32, SCAN_CLOSE, None)
+    assert rel_err(dA, r["dA"]) < pg, "dA"
+    check_close("dB", dB, _round(r["dB"], dB.dtype), dB.dtype, SCAN_CLOSE, gt)
+    check_close("dC", dC, _round(r["dC"], dC.dtype), dC.dtype, SCAN_CLOSE, gt)
     if t["D"] is not None:
-        assert rel_err(dD, r["dD"]) < gt, "dD"
+        assert rel_err(dD, r["dD"]) < pg, "dD"
     if t["delta_bias"] is not None:
-        assert rel_err(dbias, r["ddelta_bias"]) < gt, "ddelta_bias"
+        assert rel_err(dbias, r["ddelta_bias"]) < pg, "ddelta_bias"
     if t["z"] is not None:
         dz = grads[7]
         assert dz.data_ptr() == dz_buf.data_ptr()
         if lo:
-            assert rel_err(dz.float(), _round(_dz_from_saved_out(t["dout"], out, t["z"]), dt)) < gt, "dz"
+            check_close("dz", dz, _round(_dz_from_saved_out(t["dout"], out, t["z"]), dt), dt, SCAN_CLOSE, gt)
         else:
-            assert rel_err(dz.float(), r["dz"]) < gt, "dz"
+            check_close("dz", dz, r["dz"], dt, SCAN_CLOSE, gt)
 
 
 @pytest.mark.parametrize("name", golden_names("scan_"))
@@ -300,7 +310,8 @@ def test_scan_golden(name, cuda, ops):
     # oracle -- use fp32 (fwd_kernel.cuh:288-291), so ref-vs-kernel differs by ~1 ulp of the I/O dtype; the
     # reference's own test tolerance for that is rtol/atol 3e-2/5e-2 (bf16).  The 1e-3 bound is enforced
     # against the oracle (kernel semantics) in the tests below.
-    _check_scan(t, ss, exp_f, exp_b, tol=_tol(t["dtype"]) if t["dtype"] == torch.float32 else 5e-3)
+    lo = t["dtype"] != torch.float32
+    _check_scan(t, ss, exp_f, exp_b, tol=5e-3 if lo else _tol(t["dtype"]), gtol=5e-3 if lo else None)
 
 
 def _rand_scan(gen, batch, dim, N, L, G, dtype, dev, has_z=True, has_D=True, has_bias=True, softplus=True,
@@ -509,9 +520,9 @@ def test_scan_full_size_properties(cfg, batch, dim, N, L, dtype, G, cuda, ops):
         sub(t["u"]), sub(t["delta"]), t["A"][sel], t["B"][b0:b0 + 1], t["C"][b0:b0 + 1], t["D"][sel],
         sub(t["z"]), t["delta_bias"][sel], True)
     tol = _tol(dtype)
-    assert rel_err(sub(out).float(), _round(r_out, dtype)) < tol
-    assert rel_err(sub(out_z).float(), _round(r_out_z, dtype)) < tol
-    assert rel_err(x[b0, sel, -1, :], r_last[0]) < max(tol, 1e-4)
+    check_close(cfg + ".out", sub(out), _round(r_out, dtype), dtype, SCAN_CLOSE, tol)
+    check_close(cfg + ".out_z", sub(out_z), _round(r_out_z, dtype), dtype, SCAN_CLOSE, tol)
+    check_close(cfg + ".last_state", x[b0, sel, -1, :], r_last[0], torch.float32, SCAN_CLOSE, max(tol, 1e-4))
     # (d) + per-channel grads: dout nonzero only on the slice
     dout = torch.zeros_like(t["dout"])
     dout[b0, sel] = t["dout"][b0, sel]
@@ -519,12 +530,13 @@ def test_scan_full_size_properties(cfg, batch, dim, N, L, dtype, G, cuda, ops):
                True, False)
     r = cpu_oracle.selective_scan_bwd(sub(t["u"]), sub(t["delta"]), t["A"][sel], t["B"][b0:b0 + 1], t["C"][b0:b0 + 1],
                                       t["D"][sel], sub(t["z"]), t["delta_bias"][sel], sub(dout), True)
-    gt = 5e-3 if dtype != torch.float32 else 2e-4
-    assert rel_err(sub(g[0]).float(), _round(r["du"], dtype)) < gt
-    assert rel_err(sub(g[1]).float(), _round(r["ddelta"], dtype)) < gt
+    gt = 1e-3 if dtype != torch.float32 else 2e-4          # north_star: <= 1e-3 (measured: profiles/r02_parity_relerr.log)
+    check_close(cfg + ".du", sub(g[0]), _round(r["du"], dtype), dtype, SCAN_CLOSE, gt)
+    check_close(cfg + ".ddelta", sub(g[1]), _round(r["ddelta"], dtype), dtype, SCAN_CLOSE, gt)
+    check_close(cfg + ".dA", g[2][sel], r["dA"], torch.float32, SCAN_CLOSE, None)
     assert rel_err(g[2][sel], r["dA"]) < gt
-    assert rel_err(g[3][b0:b0 + 1].float(), _round(r["dB"], dtype)) < gt
-    assert rel_err(g[4][b0:b0 + 1].float(), _round(r["dC"], dtype)) < gt
+    check_close(cfg + ".dB", g[3][b0:b0 + 1], _round(r["dB"], dtype), dtype, SCAN_CLOSE, gt)
+    check_close(cfg + ".dC", g[4][b0:b0 + 1], _round(r["dC"], dtype), dtype, SCAN_CLOSE, gt)
     assert rel_err(g[5][sel], r["dD"]) < gt and rel_err(g[6][sel], r["ddelta_bias"]) < gt
     others = torch.ones(dim, dtype=torch.bool, device=cuda)
     others[sel] = False

@@ -1,34 +1,57 @@
 #!/usr/bin/env python3
-"""HBM traffic of the benchmark's hot-path kernels from two rocprofv3 --pmc passes over bench.py (FETCH_SIZE and
-WRITE_SIZE cannot share a pass on gfx950; FETCH_SIZE reports half of a wide coalesced read stream there -- see
+"""HBM traffic and VALU instruction counts of the benchmark's hot-path kernels from rocprofv3 --pmc passes over bench.py
+(FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950; FETCH_SIZE reports half of a wide coalesced read stream there --
 MI355X_MICROARCH.md, HBM section -- so reads are doubled).  Kernels are grouped by the C-ABI entry point that launches
-them; the result is bytes per entry-point launch, like roofline.achieved in bench.py.
-Usage: python tools/pmc_bench_traffic.py <dir-FETCH_SIZE-pass> <dir-WRITE_SIZE-pass> <launches-per-entry-point-json> <out.json>"""
-import csv, glob, json, os, sys
+them; launches are counted from the profile itself (dispatches of the entry point's main kernel); the record carries a
+hash of the kernel sources so that bench.py can tell a stale record from a current one.
+Usage: python tools/pmc_bench_traffic.py <dir-FETCH_SIZE-pass> <dir-WRITE_SIZE-pass> <dir-SQ_INSTS_VALU-pass | -> <out.json>"""
+import csv, glob, hashlib, json, os, sys
 from collections import defaultdict
 
-GROUPS = {"selective_scan_bwd": ("ssm_bwd",), "selective_scan_fwd": ("ssm_fwd",),
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GROUPS = {"selective_scan_bwd": ("ssm_bwd", "ssm_ls_bwd", "ssm_ls_carry_kernelILb1", "ssm_ls_carry_kernel<true>"),
+          "selective_scan_fwd": ("ssm_fwd", "ssm_ls_fwd", "ssm_ls_carry_kernelILb0", "ssm_ls_carry_kernel<false>"),
           "causal_conv1d_fwd": ("conv1d_fwd",), "causal_conv1d_bwd": ("conv1d_bwd",)}
+# one dispatch of these per entry-point call
+MAIN = {"selective_scan_bwd": ("ssm_ls_bwd_kernel", "ssm_bwd_fast_kernel", "ssm_bwd_generic_kernel"),
+        "selective_scan_fwd": ("ssm_fwd_nsplit_kernel", "ssm_fwd_generic_kernel", "Li2ELb", ", 2, true>", ", 2, false>"),
+        "causal_conv1d_fwd": ("conv1d_fwd",), "causal_conv1d_bwd": ("conv1d_bwd",)}
+
+
+def kernels_sha():
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "vivim_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "vivim_amd", "csrc", "*.cuh"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
 
 
 def total(d, counter):
-    out = defaultdict(float)
+    out, main = defaultdict(float), defaultdict(int)
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == counter:
-                for g, subs in GROUPS.items():
-                    if any(s in r["Kernel_Name"] for s in subs):
-                        out[g] += float(r["Counter_Value"])
-    return out
+            if r["Counter_Name"] != counter:
+                continue
+            for g, subs in GROUPS.items():
+                if any(s in r["Kernel_Name"] for s in subs):
+                    out[g] += float(r["Counter_Value"])
+                    if any(s in r["Kernel_Name"] for s in MAIN[g]):
+                        main[g] += 1
+    return out, main
 
 
-fetch, write = total(sys.argv[1], "FETCH_SIZE"), total(sys.argv[2], "WRITE_SIZE")
-launches = json.load(open(sys.argv[3]))          # {"selective_scan_bwd": launches in the profiled run incl. warm-up, ...}
-res = {}
-for g in GROUPS:
-    n = launches[g]
-    res[g] = {"launches_profiled": n, "fetch_KiB_per_launch": round(fetch[g] / n, 1), "write_KiB_per_launch": round(write[g] / n, 1),
-              "hbm_bytes_per_launch": int((2 * fetch[g] + write[g]) * 1024 / n)}
-json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --steps 5 --warmup 2`; reads doubled (gfx950)",
-           "per_entry_point": res}, open(sys.argv[4], "w"), indent=1)
-print(json.dumps(res, indent=1))
+if __name__ == "__main__":
+    (fetch, nf), (write, nw) = total(sys.argv[1], "FETCH_SIZE"), total(sys.argv[2], "WRITE_SIZE")
+    valu, nv = total(sys.argv[3], "SQ_INSTS_VALU") if sys.argv[3] != "-" else ({}, {})
+    res = {}
+    for g in GROUPS:
+        if not nf.get(g) or not nw.get(g):
+            continue
+        res[g] = {"launches_profiled": nf[g], "fetch_KiB_per_launch": round(fetch[g] / nf[g], 1),
+                  "write_KiB_per_launch": round(write[g] / nw[g], 1),
+                  "hbm_bytes_per_launch": int((2 * fetch[g] / nf[g] + write[g] / nw[g]) * 1024)}
+        if nv.get(g):
+            res[g]["valu_wave_insts_per_launch"] = int(valu[g] / nv[g])
+    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU passes (one counter per pass) over `bench.py --steps 5 "
+                       "--warmup 2`; reads doubled (gfx950); launches counted from the profile",
+               "kernels_sha": kernels_sha(), "per_entry_point": res}, open(sys.argv[4], "w"), indent=1)
+    print(json.dumps(res, indent=1))

@@ -58,6 +58,19 @@ def wrap(model, device=None, bucket_cap_mb=25):
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not _REHEARSE):
         return model
     ids = [device.index] if device is not None and device.type == "cuda" else None
+    # a channels-last parameter (the decode head's 1x1 `out` conv) gets a channels-last gradient, which cannot be a view of
+    # its contiguous bucket ("Grad strides do not match bucket view strides": an extra copy per step): store it densely
+    for prm in model.parameters():
+        if not prm.data.is_contiguous():
+            prm.data = prm.data.contiguous()
+        if prm.requires_grad and prm.dim() == 4 and prm.shape[2] == prm.shape[3] == 1:
+            # MIOpen returns the weight gradient of a 1x1 convolution with channels-last strides on its two size-1 axes
+            # ((768, 1, 768, 768) for a (3, 768, 1, 1) weight): the same bytes as the dense layout, but DDP compares the
+            # stride tuples and copies.  Hand it the dense strides over the same storage.
+            def dense_strides(g):
+                want = tuple(torch.empty(g.shape, device="meta").stride())
+                return g.as_strided(g.shape, want, g.storage_offset()) if g.is_contiguous() and g.stride() != want else g
+            prm.register_hook(dense_strides)
     return torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, bucket_cap_mb=bucket_cap_mb,
                                                      gradient_as_bucket_view=True)
 
@@ -81,3 +94,47 @@ def barrier(device=None):
         dist.barrier()
     if device is not None and device.type == "cuda":
         torch.cuda.synchronize(device)
+
+
+def comm_probe(step_model, run_step, sync_ms_per_step, device=None, steps=3):
+    """What the gradient exchange costs and how much of it the backward hides, measured after the
+    timed region on a world of > 1 ranks:
+      allreduce_ms  -- all the gradient bytes reduced again, alone, in bucket-sized pieces (max over ranks);
+      overlap_frac  -- 1 - (step with exchange - step without) / allreduce_ms, clamped to [0, 1]; the step without exchange
+                       runs under DDP.no_sync() (replicas drift apart afterwards: call this last).
+    -> dict (empty when the world is one rank and this is no rehearsal)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not _REHEARSE):
+        return {}
+    import time
+    out = {"n_ranks_seen": dist.get_world_size()}
+    grads = [p for p in step_model.parameters() if p.requires_grad]
+    nbytes = sum(p.numel() * p.element_size() for p in grads)
+    cap = 25 * 1024 * 1024 // 4
+    flat = torch.zeros(sum(p.numel() for p in grads), dtype=torch.float32, device=grads[0].device)
+    pieces = list(flat.split(cap))
+    cuda = device is not None and device.type == "cuda"
+
+    def once():
+        barrier(device)
+        t0 = time.perf_counter()
+        for t in pieces:
+            dist.all_reduce(t)
+        if cuda:
+            torch.cuda.synchronize(device)
+        return time.perf_counter() - t0
+    once()
+    ar = min(once() for _ in range(3))
+    out["allreduce_ms"] = round(max_over_ranks(ar, device) * 1e3, 3)
+    out["allreduce_MB"] = round(nbytes / 1e6, 1)
+    if hasattr(step_model, "no_sync"):
+        barrier(device)
+        t0 = time.perf_counter()
+        with step_model.no_sync():
+            for _ in range(steps):
+                run_step()
+        barrier(device)
+        nosync_ms = max_over_ranks((time.perf_counter() - t0) / steps, device) * 1e3
+        out["ms_per_step_no_exchange"] = round(nosync_ms, 3)
+        exposed = max(0.0, sync_ms_per_step - nosync_ms)
+        out["overlap_frac"] = round(min(1.0, max(0.0, 1.0 - exposed / max(out["allreduce_ms"], 1e-6))), 4)
+    return out
