@@ -1,2 +1,3 @@
 from vivim_amd.selective_scan_interface import (  # noqa: F401
-    MambaInnerFnNoOutProj, SelectiveScanFn, mamba_inner_fn, mamba_inner_fn_no_out_proj, selective_scan_fn)
+    BiMambaInnerFn, MambaInnerFnNoOutProj, SelectiveScanFn, bimamba_inner_fn, mamba_inner_fn, mamba_inner_fn_no_out_proj,
+    selective_scan_fn)

@@ -92,6 +92,26 @@ def mamba_inner_no_out_proj_ref(xz, conv1d_weight, conv1d_bias, x_proj_weight, d
                               delta_softplus=delta_softplus)
 
 
+def bimamba_inner_ref(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias,
+                      A, A_b, D=None, delta_bias=None, delta_softplus=True):
+    """selective_scan_interface.py:673-709 with input-dependent B and C: one conv / x_proj / dt_proj, the scan of the sequence
+    with A plus the scan of the flipped sequence with A_b (flipped back), then out_proj; returns (b, l, d_model)."""
+    l = xz.shape[-1]
+    r = delta_proj_weight.shape[1]
+    n = A.shape[-1]
+    x, z = xz.chunk(2, dim=1)
+    x = causal_conv1d_ref(x, conv1d_weight.squeeze(1), conv1d_bias, "silu")
+    bsz, d_in, _ = x.shape
+    x_dbl = F.linear(x.transpose(1, 2).reshape(bsz * l, d_in), x_proj_weight)
+    delta = (delta_proj_weight @ x_dbl[:, :r].t()).reshape(d_in, bsz, l).transpose(0, 1)
+    Bm = x_dbl[:, r:r + n].reshape(bsz, l, n).transpose(1, 2).contiguous()
+    Cm = x_dbl[:, -n:].reshape(bsz, l, n).transpose(1, 2).contiguous()
+    y = selective_scan_ref(x, delta, A, Bm, Cm, D, z=z, delta_bias=delta_bias, delta_softplus=delta_softplus)
+    y_b = selective_scan_ref(x.flip([-1]), delta.flip([-1]), A_b, Bm.flip([-1]), Cm.flip([-1]), D, z=z.flip([-1]),
+                             delta_bias=delta_bias, delta_softplus=delta_softplus)
+    return F.linear((y + y_b.flip([-1])).transpose(1, 2), out_proj_weight, out_proj_bias)
+
+
 def mamba_v3_forward_ref(hidden, p, nframes):
     """v3 tri-directional Mamba forward (mamba_simple.py:188-264) on a dict of parameters `p` with the
     module's state-dict names (in_proj.weight, conv1d{,_b,_s}.weight/bias, x_proj*.weight,

@@ -192,6 +192,29 @@ def make_inner(ssi):
              meta=np.array([b, d_inner, n, r, l]))
 
 
+def make_bimamba(ssi):
+    """bimamba_inner_ref (selective_scan_interface.py:673-709): one conv / x_proj / dt_proj, a forward scan with A and a scan
+    of the flipped sequence with A_b, summed, then out_proj.  Not on Vivim's v3 path (mamba_simple.py:125), but part of the
+    surface `mamba_ssm` exports (bimamba_inner_fn, :616-625)."""
+    for i, (name, b, d_inner, n, r, l, d_model) in enumerate([("bimamba_small", 2, 16, 8, 2, 64, 12),
+                                                             ("bimamba_odd", 1, 8, 16, 1, 37, 5)]):
+        G = gen(350 + i)
+        p = inner_params(G, d_inner, n, r)
+        p["A_b"] = -torch.arange(1, n + 1, dtype=torch.float32).repeat(d_inner, 1) * (0.5 + torch.rand(d_inner, n, generator=G))
+        p["out_w"] = torch.randn(d_model, d_inner, generator=G) * d_inner ** -0.5
+        p["out_b"] = torch.randn(d_model, generator=G) * 0.1
+        xz = torch.randn(b, 2 * d_inner, l, generator=G)
+        dout = torch.randn(b, l, d_model, generator=G)
+        for t in [xz] + list(p.values()):
+            t.requires_grad_(True)
+        y = ssi.bimamba_inner_ref(xz, p["conv_w"], p["conv_b"], p["x_proj"], p["dt_proj"], p["out_w"], p["out_b"],
+                                  p["A"], p["A_b"], None, None, p["D"], delta_bias=p["dt_bias"], delta_softplus=True)
+        y.backward(dout)
+        save(name, xz=npf(xz), dout=npf(dout), out=npf(y), dxz=npf(xz.grad),
+             **{k: npf(v) for k, v in p.items()}, **{"d" + k: npf(v.grad) for k, v in p.items()},
+             meta=np.array([b, d_inner, n, r, l, d_model]))
+
+
 def make_module(cci, ssi, only=None):
     """v3 Mamba module forward/backward (mamba_simple.py:188-264).  The module's fast path calls
     mamba_inner_fn_no_out_proj (CUDA); it is rebound to the reference refs composed as in make_inner."""
@@ -211,7 +234,9 @@ def make_module(cci, ssi, only=None):
                                                                # token counts that are multiples of 8: the build's
                                                                # grouped three-direction path (vivim_amd/mamba_simple.py)
                                                                ("module_nf5_hw8", 2, 16, 16, 2, 5, 8),
-                                                               ("module_nf3_hw16", 1, 32, 16, 2, 3, 16)]):
+                                                               ("module_nf3_hw16", 1, 32, 16, 2, 3, 16),
+                                                               # BASELINE.json configs[4]: d_state 64, expand 4, 8 frames
+                                                               ("module_n64_e4_nf8", 1, 16, 64, 4, 8, 16)]):
         if only and name not in only:
             continue
         torch.manual_seed(400 + i)
@@ -279,6 +304,8 @@ if __name__ == "__main__":
         make_scan(ssi)
         make_conv(cci)
         make_inner(ssi)
+    if not only or "bimamba" in only:
+        make_bimamba(ssi)
     if not only or "update" in only:
         make_update(cci)
     mods = {n for n in only if n.startswith("module_")}

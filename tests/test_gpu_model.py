@@ -29,6 +29,67 @@ def test_fused_inner_op_golden(name, cuda):
         assert rel_err(p[k].grad, g["d" + k]) < 2e-4, k
 
 
+@pytest.mark.parametrize("name", golden_names("bimamba_"))
+def test_bimamba_inner_fn_golden(name, cuda):
+    """bimamba_inner_fn (selective_scan_interface.py:437-603, 616-625) forward + every gradient vs the reference's
+    bimamba_inner_ref (:673-709).  (The reference's own test of it compares the function with itself,
+    tests/ops/test_selective_scan.py:314-320.)"""
+    from mamba_ssm import bimamba_inner_fn
+    g = load_golden(name)
+    names = ["conv_w", "conv_b", "x_proj", "dt_proj", "out_w", "out_b", "A", "A_b", "D", "dt_bias"]
+    p = {k: g[k].to(cuda).requires_grad_(True) for k in names}
+    b, d_inner, n, r, L, d_model = g["meta"]
+    xz = g["xz"].to(cuda).requires_grad_(True)
+    out = bimamba_inner_fn(xz, p["conv_w"], p["conv_b"], p["x_proj"], p["dt_proj"], p["out_w"], p["out_b"],
+                           p["A"], p["A_b"], None, None, p["D"], delta_bias=p["dt_bias"], delta_softplus=True)
+    assert out.shape == (b, L, d_model)
+    check_close("bimamba.out", out, g["out"], torch.float32, SCAN_CLOSE, 2e-5)
+    out.backward(g["dout"].to(cuda))
+    check_close("bimamba.dxz", xz.grad, g["dxz"], torch.float32, SCAN_CLOSE, 2e-4)
+    for k in names:
+        assert rel_err(p[k].grad, g["d" + k]) < 2e-4, k
+
+
+def test_bimamba_inner_fn_constant_BC_matches_two_scans(cuda):
+    """Constant (dim, dstate) B and C (the other branch of :474-492) against the composition the reference's ref spells out:
+    two selective_scan_fn calls, the second on flipped inputs."""
+    from mamba_ssm import bimamba_inner_fn, selective_scan_fn
+    from causal_conv1d import causal_conv1d_fn
+    gen = torch.Generator().manual_seed(5)
+    b, d, n, r, L, e = 2, 24, 16, 2, 96, 10
+    mk = lambda *s, k=1.0: (torch.randn(*s, generator=gen) * k).to(cuda).requires_grad_(True)
+    xz, cw, cb = mk(b, 2 * d, L), mk(d, 1, 4, k=0.3), mk(d, k=0.1)
+    xp, dp, ow, ob = mk(r + 2 * n, d, k=d ** -0.5), mk(d, r, k=r ** -0.5), mk(e, d, k=d ** -0.5), mk(e, k=0.1)
+    A = (-torch.rand(d, n, generator=gen) - 0.1).to(cuda).requires_grad_(True)
+    A_b = (-torch.rand(d, n, generator=gen) - 0.1).to(cuda).requires_grad_(True)
+    Bc, Cc, D, bias = mk(d, n), mk(d, n), mk(d), mk(d, k=0.2)
+    leaves = [xz, cw, cb, xp, dp, ow, ob, A, A_b, Bc, Cc, D, bias]
+    dout = torch.randn(b, L, e, generator=gen).to(cuda)
+
+    def composed():
+        x, z = xz.chunk(2, dim=1)
+        x = causal_conv1d_fn(x, cw.squeeze(1), cb, "silu")
+        x_dbl = torch.nn.functional.linear(x.transpose(1, 2).reshape(b * L, d), xp)
+        delta = (dp @ x_dbl[:, :r].t()).view(d, b, L).transpose(0, 1).contiguous()
+        y = selective_scan_fn(x, delta, A, Bc, Cc, D, z=z, delta_bias=bias, delta_softplus=True)
+        y_b = selective_scan_fn(x.flip([-1]), delta.flip([-1]), A_b, Bc, Cc, D, z=z.flip([-1]), delta_bias=bias,
+                                delta_softplus=True)
+        return torch.nn.functional.linear((y + y_b.flip([-1])).transpose(1, 2), ow, ob)
+
+    def grads(fn):
+        for t in leaves:
+            t.grad = None
+        out = fn()
+        out.backward(dout)
+        return out.detach(), [t.grad.clone() for t in leaves]
+    o1, g1 = grads(lambda: bimamba_inner_fn(xz, cw, cb, xp, dp, ow, ob, A, A_b, Bc, Cc, D, delta_bias=bias,
+                                            delta_softplus=True))
+    o2, g2 = grads(composed)
+    assert rel_err(o1, o2) < 2e-5
+    for i, (a, c) in enumerate(zip(g1, g2)):
+        assert rel_err(a, c) < 2e-4, i
+
+
 @pytest.mark.parametrize("name", golden_names("module_"))
 def test_v3_module_golden(name, cuda):
     """Mamba(bimamba_type='v3') forward/backward vs the reference module run on the reference refs

@@ -86,6 +86,25 @@ def test_inner_op_matches_reference(name):
         assert rel_err(p[k].grad, g["d" + k]) < 1e-4, k
 
 
+BIMAMBA_PARAMS = ["conv_w", "conv_b", "x_proj", "dt_proj", "out_w", "out_b", "A", "A_b", "D", "dt_bias"]
+
+
+@pytest.mark.parametrize("name", golden_names("bimamba_"))
+def test_bimamba_inner_matches_reference(name):
+    """The restatement of bimamba_inner_ref (selective_scan_interface.py:673-709) against the reference's own output and
+    autograd gradients."""
+    g = load_golden(name)
+    p = {k: g[k].clone().requires_grad_(True) for k in BIMAMBA_PARAMS}
+    xz = g["xz"].clone().requires_grad_(True)
+    out = ref_torch.bimamba_inner_ref(xz, p["conv_w"], p["conv_b"], p["x_proj"], p["dt_proj"], p["out_w"], p["out_b"],
+                                      p["A"], p["A_b"], p["D"], p["dt_bias"], True)
+    assert rel_err(out, g["out"]) < 1e-5
+    out.backward(g["dout"])
+    assert rel_err(xz.grad, g["dxz"]) < 1e-4
+    for k in BIMAMBA_PARAMS:
+        assert rel_err(p[k].grad, g["d" + k]) < 1e-4, k
+
+
 @pytest.mark.parametrize("name", golden_names("module_"))
 def test_v3_module_matches_reference(name):
     g = load_golden(name)

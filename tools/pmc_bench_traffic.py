@@ -14,7 +14,9 @@ GROUPS = {"selective_scan_bwd": ("ssm_bwd", "ssm_ls_bwd", "ssm_ls_carry_kernelIL
           "causal_conv1d_fwd": ("conv1d_fwd",), "causal_conv1d_bwd": ("conv1d_bwd",)}
 # one dispatch of these per entry-point call
 MAIN = {"selective_scan_bwd": ("ssm_ls_bwd_kernel", "ssm_bwd_fast_kernel", "ssm_bwd_generic_kernel"),
-        "selective_scan_fwd": ("ssm_fwd_nsplit_kernel", "ssm_fwd_generic_kernel", "Li2ELb", ", 2, true>", ", 2, false>"),
+        "selective_scan_fwd": ("ssm_fwd_nsplit_kernel", "ssm_fwd_generic_kernel",
+                               "ssm_fwd_bc_kernel",            # lanes=channels: once per call (its two passes share a name)
+                               "ELi2ELb", ", 2, true>", ", 2, false>"),       # lanes=states: PASS == 2
         "causal_conv1d_fwd": ("conv1d_fwd",), "causal_conv1d_bwd": ("conv1d_bwd",)}
 
 

@@ -4,6 +4,7 @@ Same names, argument order, saved-tensor policy and return tuples as the referen
 mamba/mamba_ssm/ops/selective_scan_interface.py:
   SelectiveScanFn / selective_scan_fn                       :14-83
   MambaInnerFnNoOutProj / mamba_inner_fn_no_out_proj        :155-289, :627-633   (what Vivim calls)
+  BiMambaInnerFn / bimamba_inner_fn                         :437-603, :616-625
   mamba_inner_fn                                            :606-615  (composition with out_proj)
 The CUDA extension calls are replaced by vivim_amd.selective_scan_cuda / causal_conv1d_cuda (gfx950
 kernels behind the C ABI); the GEMMs inside the fused op stay on PyTorch-ROCm (hipBLASLt), as in the
@@ -303,3 +304,157 @@ def mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_wei
     y = mamba_inner_fn_no_out_proj(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
                                    A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus)
     return F.linear(y.transpose(1, 2), out_proj_weight, out_proj_bias)
+
+
+class BiMambaInnerFn(torch.autograd.Function):
+    """The reference's BiMambaInnerFn (:437-603): one conv / x_proj / dt_proj, the scan of the sequence with A plus the scan
+    of the time-reversed sequence with A_b (reversed back), out_proj; same arguments, same saved-tensor policy
+    (checkpoint_lvl = 1: conv1d_out and delta are rebuilt in the backward), same gradient tuple.  Dead code in Vivim's fork
+    (mamba_simple.py:125 asserts v3) but part of what `mamba_ssm` exports (:616-625).
+
+    Where the reference launches the scan twice per pass (:499-505, :541-553), the two directions here sit side by side on
+    the channel axis -- channels [0, d) the sequence, [d, 2d) its reversal, B / C as two groups -- so each pass is ONE
+    forward and ONE backward scan launch with n_groups = 2 and twice the independent work per launch."""
+
+    @staticmethod
+    def _both(t, dim=1):
+        """(b, c, l) -> (b, 2c, l): the tensor and its time reversal side by side on `dim`."""
+        return torch.cat([t, t.flip([-1])], dim=dim)
+
+    @staticmethod
+    def _fold(t2):
+        """(b, 2c, l) -> (b, c, l): first half + reversed second half."""
+        c = t2.shape[1] // 2
+        return t2[:, :c] + t2[:, c:].flip([-1])
+
+    @staticmethod
+    def _stack(conv1d_out, delta, z, B, C, A, A_b, D, delta_bias, var_B, var_C):
+        both = BiMambaInnerFn._both
+        twice = lambda t: None if t is None else torch.cat([t, t])
+        return (both(conv1d_out), both(delta), both(z), both(B) if var_B else twice(B), both(C) if var_C else twice(C),
+                torch.cat([A, A_b]), twice(D), twice(delta_bias))
+
+    @staticmethod
+    def _project(x_dbl, delta_proj_weight, B, C, B_proj_bias, C_proj_bias, batch, L, N):
+        R = delta_proj_weight.shape[1]
+        d_inner = delta_proj_weight.shape[0]
+        delta = (delta_proj_weight @ x_dbl[:, :R].t()).view(d_inner, batch, L).transpose(0, 1)
+        if B is None:
+            B = x_dbl[:, R:R + N]
+            if B_proj_bias is not None:
+                B = B + B_proj_bias.to(B.dtype)
+            B = B.view(batch, L, N).transpose(1, 2).unsqueeze(1)           # (b, 1, N, l) view; `_both` copies it
+        if C is None:
+            C = x_dbl[:, -N:]
+            if C_proj_bias is not None:
+                C = C + C_proj_bias.to(C.dtype)
+            C = C.view(batch, L, N).transpose(1, 2).unsqueeze(1)
+        return delta, B, C
+
+    @staticmethod
+    @custom_fwd(device_type="cuda")
+    def forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias,
+                A, A_b, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None,
+                delta_softplus=True, checkpoint_lvl=1):
+        assert checkpoint_lvl in (0, 1)
+        if A.is_complex() or A_b.is_complex():
+            raise NotImplementedError("complex A is outside this build (the reference asserts a real A_b, :503)")
+        batch, _, L = xz.shape
+        N = A.shape[-1]
+        if torch.is_autocast_enabled("cuda"):
+            amp_dtype = torch.get_autocast_dtype("cuda")
+            x_proj_weight = x_proj_weight.to(amp_dtype)
+            delta_proj_weight = delta_proj_weight.to(amp_dtype)
+            out_proj_weight = out_proj_weight.to(amp_dtype)
+            out_proj_bias = out_proj_bias.to(amp_dtype) if out_proj_bias is not None else None
+        xz = _unit_l(xz)
+        conv1d_weight = conv1d_weight.squeeze(1)
+        x, z = xz.chunk(2, dim=1)
+        conv1d_bias = conv1d_bias.contiguous() if conv1d_bias is not None else None
+        conv1d_out = causal_conv1d_cuda.causal_conv1d_fwd(x, conv1d_weight, conv1d_bias, True)
+        d_inner = conv1d_out.shape[1]
+        x_dbl = F.linear(conv1d_out.transpose(1, 2).reshape(batch * L, d_inner), x_proj_weight)
+        ctx.is_variable_B, ctx.is_variable_C = B is None, C is None
+        ctx.B_proj_bias, ctx.C_proj_bias = B_proj_bias, C_proj_bias
+        delta, Bv, Cv = BiMambaInnerFn._project(x_dbl, delta_proj_weight, B, C, B_proj_bias, C_proj_bias, batch, L, N)
+        u2, delta2, z2, B2, C2, A2, D2, bias2 = BiMambaInnerFn._stack(
+            conv1d_out, delta, z, Bv, Cv, A, A_b, D, delta_bias, ctx.is_variable_B, ctx.is_variable_C)
+        out2, scan_intermediates, out_z2 = selective_scan_cuda.fwd(u2, delta2, A2, B2, C2, D2, z2, bias2, delta_softplus)
+        out_z = BiMambaInnerFn._fold(out_z2)
+        ctx.delta_softplus = delta_softplus
+        ctx.out_proj_bias_is_None = out_proj_bias is None
+        ctx.checkpoint_lvl = checkpoint_lvl
+        if checkpoint_lvl >= 1:
+            conv1d_out = delta = None
+        ctx.save_for_backward(xz, conv1d_weight, conv1d_bias, x_dbl, x_proj_weight, delta_proj_weight, out_proj_weight,
+                              conv1d_out, delta, A, A_b, B, C, D, delta_bias, scan_intermediates, out2)
+        return F.linear(out_z.transpose(1, 2), out_proj_weight, out_proj_bias)
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, dout):
+        (xz, conv1d_weight, conv1d_bias, x_dbl, x_proj_weight, delta_proj_weight, out_proj_weight, conv1d_out, delta,
+         A, A_b, B, C, D, delta_bias, scan_intermediates, out2) = ctx.saved_tensors
+        batch, _, L = xz.shape
+        R = delta_proj_weight.shape[1]
+        N = A.shape[-1]
+        x, z = xz.chunk(2, dim=1)
+        d_inner = x.shape[1]
+        if ctx.checkpoint_lvl == 1:
+            conv1d_out = causal_conv1d_cuda.causal_conv1d_fwd(x, conv1d_weight, conv1d_bias, True)
+        delta_r, Bv, Cv = BiMambaInnerFn._project(x_dbl, delta_proj_weight, B, C, ctx.B_proj_bias, ctx.C_proj_bias,
+                                                  batch, L, N)
+        delta = delta_r if ctx.checkpoint_lvl == 1 else delta
+        u2, delta2, z2, B2, C2, A2, D2, bias2 = BiMambaInnerFn._stack(
+            conv1d_out, delta, z, Bv, Cv, A, A_b, D, delta_bias, ctx.is_variable_B, ctx.is_variable_C)
+        dout = dout.reshape(batch * L, -1).to(out_proj_weight.dtype)        # ((b l), e)
+        dout_y = (out_proj_weight.t() @ dout.t()).view(d_inner, batch, L).transpose(0, 1)
+        dconv2, ddelta2, dA2, dB2, dC2, dD2, dbias2, dz2, out_z2 = selective_scan_cuda.bwd(
+            u2, delta2, A2, B2, C2, D2, z2, bias2, BiMambaInnerFn._both(dout_y), scan_intermediates, out2, None,
+            ctx.delta_softplus, True)
+        fold = BiMambaInnerFn._fold
+        dxz = torch.empty_like(xz)
+        dx, dz = dxz.chunk(2, dim=1)
+        dz.copy_(fold(dz2))
+        out_z = fold(out_z2)
+        dout_proj_weight = dout.t() @ out_z.transpose(1, 2).reshape(batch * L, d_inner)
+        dout_proj_bias = dout.sum(0) if not ctx.out_proj_bias_is_None else None
+        dA, dA_b = dA2[:d_inner], dA2[d_inner:]
+        halves = lambda t: t[:d_inner] + t[d_inner:]
+        dx_dbl = torch.empty_like(x_dbl)
+        dB_proj_bias = dC_proj_bias = None
+        if ctx.is_variable_B:
+            dB = fold(dB2).squeeze(1).transpose(1, 2).reshape(batch * L, N)
+            dB_proj_bias = dB.sum(0) if ctx.B_proj_bias is not None else None
+            dx_dbl[:, R:R + N] = dB
+            dB = None
+        else:
+            dB = halves(dB2)
+        if ctx.is_variable_C:
+            dC = fold(dC2).squeeze(1).transpose(1, 2).reshape(batch * L, N)
+            dC_proj_bias = dC.sum(0) if ctx.C_proj_bias is not None else None
+            dx_dbl[:, -N:] = dC
+            dC = None
+        else:
+            dC = halves(dC2)
+        ddelta = fold(ddelta2).transpose(0, 1).reshape(d_inner, batch * L)
+        ddelta_proj_weight = ddelta @ x_dbl[:, :R]
+        dx_dbl[:, :R] = ddelta.t() @ delta_proj_weight
+        dconv1d_out = fold(dconv2).transpose(0, 1).reshape(d_inner, batch * L)
+        dx_proj_weight = dx_dbl.t() @ conv1d_out.transpose(1, 2).reshape(batch * L, d_inner)
+        dconv1d_out = torch.addmm(dconv1d_out, x_proj_weight.t(), dx_dbl.t())
+        dconv1d_out = dconv1d_out.view(d_inner, batch, L).transpose(0, 1)
+        dx, dconv1d_weight, dconv1d_bias = causal_conv1d_cuda.causal_conv1d_bwd(
+            x, conv1d_weight, conv1d_bias, dconv1d_out, dx, True)
+        return (dxz, dconv1d_weight.unsqueeze(1), dconv1d_bias if conv1d_bias is not None else None,
+                dx_proj_weight, ddelta_proj_weight, dout_proj_weight, dout_proj_bias, dA, dA_b, dB, dC,
+                halves(dD2) if D is not None else None, halves(dbias2) if delta_bias is not None else None,
+                dB_proj_bias, dC_proj_bias, None, None)
+
+
+def bimamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias,
+                     A, A_b, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None,
+                     delta_softplus=True):
+    """xz: (batch, 2*d_inner, seqlen) -> (batch, seqlen, d_model); selective_scan_interface.py:616-625."""
+    return BiMambaInnerFn.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
+                                out_proj_bias, A, A_b, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus)
