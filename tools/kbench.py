@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--groups", type=int, default=1)
     ap.add_argument("--cold", type=int, default=1)
     ap.add_argument("--ceiling", action="store_true")
+    ap.add_argument("--pad", type=int, default=0, help="extra elements between the rows of the inputs (row stride L + pad)")
     a = ap.parse_args()
     B, nf, img, N, expand, dt = CONFIGS[a.config]
     s = torch.finfo(dt).bits // 8
@@ -70,7 +71,8 @@ def main():
         G = a.groups
         D = DIMS[st] * expand * G
         L = nf * (img // STRIDES[st]) ** 2
-        mk = lambda *sh: torch.randn(*sh, device=dev).to(dt)
+        P = a.pad
+        mk = lambda *sh: torch.randn(*sh[:-1], sh[-1] + P, device=dev).to(dt)[..., :sh[-1]]
         strided = (lambda: mk(D, B, L).transpose(0, 1)) if G == 1 else (lambda: mk(B, D, L))
         A = -torch.arange(1, N + 1, device=dev, dtype=torch.float32).repeat(D, 1)
         Dv, bias = torch.ones(D, device=dev), torch.full((D,), -4.0, device=dev)
@@ -78,7 +80,7 @@ def main():
         sets = []
         for _ in range(max(1, a.cold)):
             u, z, dout = strided(), strided(), strided()
-            delta = (0.2 * torch.randn(D, B, L, device=dev)).to(dt).transpose(0, 1) if G == 1 else (0.2 * torch.randn(B, D, L, device=dev)).to(dt)
+            delta = 0.2 * strided()
             Bm, Cm = mk(B, G, N, L), mk(B, G, N, L)
             out, x, out_z = ss.fwd(u, delta, A, Bm, Cm, Dv, z, bias, True)
             sets.append((u, delta, z, dout, Bm, Cm, out, x, torch.empty_like(z)))

@@ -1,0 +1,16 @@
+#!/bin/bash
+# The three PMC passes of measure_round.sh alone (one counter per pass, kernel trace only) + the traffic record.
+#   gpurun --timeout 1000 -- 'bash tools/pmc_round.sh r02_v2'
+set -e -o pipefail
+tag=${1:?tag}
+root=${GRAFT_REPO_ROOT:-/root/repo}
+out=$root/gpurun_out
+mkdir -p "$out"
+cd /tmp && export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$out/pmc_$c" -o b -- python3 "$root/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-by-config > "$out/pmc_$c.log" 2>&1
+  echo "pass $c done"
+done
+cd "$root"
+python tools/pmc_bench_traffic.py "$out/pmc_FETCH_SIZE" "$out/pmc_WRITE_SIZE" "$out/pmc_SQ_INSTS_VALU" "$out/${tag}_bench_pmc_traffic.json"
+rm -rf "$out/pmc_FETCH_SIZE" "$out/pmc_WRITE_SIZE" "$out/pmc_SQ_INSTS_VALU"

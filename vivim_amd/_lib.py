@@ -252,6 +252,15 @@ def empty(shape, dtype, device):
     return _guarded_storage(n * torch.empty((), dtype=dtype).element_size(), device).view(dtype).view(shape)
 
 
+def zeros(n, device):
+    """A zeroed fp32 accumulator of n elements (dA / dB / dC / dD / dbias, dweight / dbias of the convolutions: what the
+    kernels ADD into), or its canary-bracketed twin under VIVIM_GUARD=1."""
+    import torch
+    if not GUARD:
+        return torch.zeros(n, dtype=torch.float32, device=device)
+    return _guarded_storage(4 * n, device).view(torch.float32).zero_()
+
+
 def empty_like(t):
     """torch.empty_like (dense, same strides), or its canary-bracketed twin under VIVIM_GUARD=1."""
     import torch

@@ -94,7 +94,7 @@ def causal_conv1d_bwd(x, weight, bias_, dout, dx_, silu_activation):
             if dx.stride(2) != 1:
                 dx = _lib.empty(tuple(x.shape), x.dtype, x.device)
     nw = dim * width                                  # one zero-filled fp32 accumulator for dweight | dbias: one fill
-    acc = torch.zeros(nw + (dim if bias_ is not None else 0), device=x.device, dtype=torch.float32)
+    acc = _lib.zeros(nw + (dim if bias_ is not None else 0), x.device)
     dweight = acc[:nw].view(dim, width)
     dbias = acc[nw:] if bias_ is not None else None
     P = _lib.ConvBwdParams()

@@ -63,7 +63,7 @@ class DepthwiseConvTokensFn(torch.autograd.Function):
             dy = dy.contiguous()
         dx = _run_fwd(dy, wt, None, (D, H, W), True) if ctx.needs_input_grad[0] else None
         B, L, C = x.shape
-        acc = torch.zeros(wt.shape[0] * C + C, device=x.device, dtype=torch.float32)
+        acc = _lib.zeros(wt.shape[0] * C + C, x.device)
         P = _lib.DwConvWgradParams()
         P.batch, P.depth, P.height, P.width, P.channels = B, D, H, W, C
         P.kd, P.itype = wt.shape[0] // 9, _DT[x.dtype]

@@ -151,7 +151,7 @@ def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softp
     # fp32 accumulators (selective_scan.cpp:458-466) carved out of ONE zero-filled buffer: one memset
     # instead of five, and dB|dC are adjacent so their cast to the input dtype is one kernel too.
     nB, nC, nA = B.numel(), C.numel(), A.numel()
-    acc = torch.zeros(nB + nC + nA + 2 * dim, device=u.device, dtype=torch.float32)
+    acc = _lib.zeros(nB + nC + nA + 2 * dim, u.device)
     dB = acc[:nB].view(B.shape)
     dC = acc[nB:nB + nC].view(C.shape)
     dA = acc[nB + nC:nB + nC + nA].view(A.shape)
