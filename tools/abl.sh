@@ -1,0 +1,21 @@
+#!/bin/bash
+# Build timing-ablation variants of the lanes=states backward (scan_ls.hip, -DLS_ABL=n: results are wrong, only the time
+# means something) next to the product library:  bash tools/abl.sh build 1 2 3 ...   /   bash tools/abl.sh run 1 2 3 ...
+set -e
+cd "$(dirname "$0")/../vivim_amd/csrc"
+mode=$1; shift
+mkdir -p abl
+if [ "$mode" = build ]; then
+  for n in "$@"; do
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -DLS_ABL=$n -Rpass-analysis=kernel-resource-usage -c scan_ls.hip -o abl/scan_ls_$n.o 2> abl/scan_ls_$n.res
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o abl/libvivim_abl_$n.so capi.o conv1d.o conv1d_cl.o scan_fwd.o scan_fwd_chan.o abl/scan_ls_$n.o scan_bwd.o dwconv.o dirmap.o update.o
+    echo "built abl $n"
+  done
+else
+  cd ../..
+  for n in "$@"; do
+    echo "== LS_ABL=$n"
+    VIVIM_LIB=$PWD/vivim_amd/csrc/abl/libvivim_abl_$n.so VIVIM_BWD_VARIANT=4 python tools/kbench.py --config 3 --stages 0 --kernels sb --iters 6 | grep stage
+    VIVIM_LIB=$PWD/vivim_amd/csrc/abl/libvivim_abl_$n.so VIVIM_BWD_VARIANT=4 python tools/kbench.py --config 2 --groups 3 --stages 1 --kernels sb --iters 20 | grep stage
+  done
+fi

@@ -413,8 +413,13 @@ __device__ __forceinline__ void ls_tie(int& v, float result) { asm volatile("" :
 // (the unrolled first version: 4 x the code, its scalar state spilled to VGPR lanes).  The activations of step i + 1 are
 // requested before step i is computed.
 // =========================================================================================================================
+// LS_ABL: timing experiments of tools/abl.sh (results are WRONG for any value but 0; never set in the product build).
+#ifndef LS_ABL
+#define LS_ABL 0
+#endif
+constexpr int kAbl = LS_ABL;
 template <typename T, int NS, bool HAS_Z>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NS == 16 ? 3 : 2, 3))) ssm_ls_bwd_kernel(const vivim_ssm_bwd_params p, const LsSeg sg) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kAbl == 8 ? 4 : (NS == 16 ? 3 : 2), kAbl == 8 ? 4 : 3))) ssm_ls_bwd_kernel(const vivim_ssm_bwd_params p, const LsSeg sg) {
     typedef LsGeom<NS> G;
     constexpr int RPS = G::RPS, SPW = G::SPW, CPW = G::CPW, CPR = kLsCPR;
     const vivim_ssm_fwd_params& f = p.f;
@@ -510,14 +515,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NS == 
         const int d = dwave + rowch + c;
         const bool cv = d < d_end;
         const int chu = min(dwave + c, d_end - 1);
-        const bool ok = cv && t < L && tile >= tile_lo;       // past the segment's last step: nothing is used
+        const bool ok = kAbl != 4 && cv && t < L && tile >= tile_lo;   // past the segment's last step: nothing is used
         r.uu = tu.ld_raw(chu, t, ok);
         r.raw = tdl.ld_raw(chu, t, ok);
         r.dy = tdo.ld_raw(chu, t, ok);
         r.zf = 0.0f; r.of = 0.0f;
         if (HAS_Z) { r.zf = tz.ld_raw(q, chu, t, ok); r.of = to.ld_raw(q, chu, t, ok); }
         const int blk = tile / RPS;
-        r.hin = tx.ld_raw(q, chu, (blk - 1) * NS + n, blk > 0 && cv && tile >= tile_lo);
+        r.hin = tx.ld_raw(q, chu, (blk - 1) * NS + n, kAbl != 4 && blk > 0 && cv && tile >= tile_lo);
         return r;
     };
 
@@ -532,6 +537,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NS == 
     int p_chu = min(dwave, d_end - 1), p_t = 0;
     bool p_st = false;
     auto flush = [&]() __attribute__((always_inline)) {
+        if constexpr (kAbl == 3) return;
         const ls_kargs qs = ls_fresh_kargs();
         if (HAS_Z) {
             tdz.st(qs, p_chu, p_t, p_st, p_dz);
@@ -566,7 +572,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NS == 
         for (int k = 0; k < 16; ++k) { dBv[k] = 0.0f; dCv[k] = 0.0f; }
         ls_arrive(Bv);
         ls_arrive(Cv);
-        const bool stage_next = W == 4 && bc_vec && tile - 1 >= tile_lo;   // (a tile left of another one is whole)
+        const bool stage_next = kAbl != 1 && W == 4 && bc_vec && tile - 1 >= tile_lo;   // (a tile left of another one is whole)
         u32x4 sb = {0u, 0u, 0u, 0u}, sc = {0u, 0u, 0u, 0u};
 #pragma unroll 1
         for (int c = 0; c < CPR; ++c) {
@@ -641,6 +647,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NS == 
                 float hp = h_in;
                 sfor<0, 16>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
+                    if constexpr (kAbl == 6) { a[k] = A2; h[k] = hp + Bv[k]; return; }
                     a[k] = fast_exp2(tok<k>(dl) * A2);
                     hp = tok_fma<k>(a[k] * hp, w, Bv[k]);                                  // h_t = a_t h_{t-1} + d_t u_t B_t
                     h[k] = hp;
@@ -660,6 +667,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NS == 
                     if constexpr (k & 1) dA1 = tok_fma<k>(dA1, dl, x); else dA0 = tok_fma<k>(dA0, dl, x);   // two chains
                     dBv[k] = tok_fma<k>(dBv[k], w, gk);
                     dCv[k] = tok_fma<k>(dCv[k], dy, h[k]);
+                    if constexpr (kAbl == 7) { if (k == 0) { S1 = s1[0] + s1[5] + s1[15]; S2 = s2[0] + s2[7] + s2[15]; } return; }
                     ls_reduce_down<k>(s1, z1, w1, v1, S1, li);
                     ls_reduce_down<k>(s2, z2, w2, v2, S2, li);
                 });
@@ -679,7 +687,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NS == 
         // Both barriers sit around the slot writes: the first says "everybody is done reading the previous tile's slots and
         // this tile's staged rows", the second "slots and the next tile's rows are written".  Back to back, the second
         // finds the waves already aligned; spaced (one before, one after the reduction) they cost two synchronisations.
-        lds_barrier();
+        if constexpr (kAbl == 1) continue;
+        if constexpr (kAbl != 2) lds_barrier();
         if (stage_next && tid < PT) {
             *reinterpret_cast<u32x4*>(stage + tid * 16) = sb;
             *reinterpret_cast<u32x4*>(stage + (PT + tid) * 16) = sc;
@@ -690,7 +699,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NS == 
             *reinterpret_cast<float4*>(slot + q * 4) = float4{dBv[q * 4], dBv[q * 4 + 1], dBv[q * 4 + 2], dBv[q * 4 + 3]};
             *reinterpret_cast<float4*>(slot + NS * 16 + q * 4) = float4{dCv[q * 4], dCv[q * 4 + 1], dCv[q * 4 + 2], dCv[q * 4 + 3]};
         }
-        lds_barrier();
+        if constexpr (kAbl != 2) lds_barrier();
         {
             const int nsrc = W * SPW;
             for (int e = tid; e < 2 * NS * 16; e += blockDim.x) {
