@@ -111,6 +111,51 @@ def test_v3_module_golden(name, cuda):
         assert rel_err(v.grad, g["grad__" + k.replace(".", "__")]) < 5e-4, k
 
 
+def test_fused_parameter_storage(cuda, monkeypatch):
+    """The grouped path reads the three directions' parameters from one persistent (3, ...) buffer per kind, of which the
+    Parameters are views (mamba_simple.Mamba._fuse): no per-step cat / stack.  Names and shapes are the reference's
+    (mamba_simple.py:69-123), gradients reach every Parameter and equal those of the three-call composition, an in-place
+    optimizer update is seen by the next forward, and a storage swap (`.half().float()`) is detected and re-fused."""
+    from mamba_ssm import Mamba
+    torch.manual_seed(3)
+    m = Mamba(d_model=32, d_state=16, bimamba_type="v3", nframes=3).to(cuda)
+    names = sorted(n for n, _ in m.named_parameters())
+    x = torch.randn(2, 3 * 16, 32, device=cuda, requires_grad=True)
+
+    def run():
+        for p in m.parameters():
+            p.grad = None
+        y = m(x)
+        y.square().mean().backward()
+        return y.detach(), {n: p.grad.clone() for n, p in m.named_parameters()}
+    y1, g1 = run()
+    assert sorted(n for n, _ in m.named_parameters()) == names and set(g1) == set(names)
+    buf = m._fused[2]
+    assert buf.shape == (3,) + tuple(m.x_proj.weight.shape)
+    assert [m.x_proj.weight.data_ptr(), m.x_proj_b.weight.data_ptr(), m.x_proj_s.weight.data_ptr()] == \
+        [buf[g].data_ptr() for g in range(3)]
+    monkeypatch.setenv("VIVIM_SEPARATE_DIRECTIONS", "1")
+    y2, g2 = run()
+    monkeypatch.delenv("VIVIM_SEPARATE_DIRECTIONS")
+    assert rel_err(y1, y2) < 2e-5
+    for n in names:
+        assert rel_err(g1[n], g2[n]) < 2e-4, n
+    with torch.no_grad():                                   # an optimizer step in place
+        for p in m.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    assert m._fused[2].data_ptr() == m.x_proj.weight.data_ptr()
+    y3, _ = run()
+    monkeypatch.setenv("VIVIM_SEPARATE_DIRECTIONS", "1")
+    y4, _ = run()
+    monkeypatch.delenv("VIVIM_SEPARATE_DIRECTIONS")
+    assert rel_err(y3, y4) < 2e-5 and rel_err(y3, y1) > 1e-3
+    m.half().float()                                        # new storage for every Parameter
+    assert m._fused[2].data_ptr() != m.x_proj.weight.data_ptr()
+    y5, _ = run()
+    assert m._fused[2].data_ptr() == m.x_proj.weight.data_ptr()
+    assert rel_err(y5, y3) < 2e-3                           # the fp16 round trip of the weights
+
+
 def test_module_nframes_override_and_autocast(cuda):
     """clip_length != 5 works (reference hard-codes 5, mamba_simple.py:54) and bf16 autocast runs the
     bf16 kernels with fp32 parameters (custom_fwd contract, selective_scan_interface.py:158-171)."""

@@ -25,6 +25,22 @@ from .selective_scan_interface import mamba_inner_fn_no_out_proj, mamba_inner_gr
 from .selective_state_update import selective_state_update
 
 _DIRECTIONS = ("", "_b", "_s")     # forward in time, backward in time, spatial (pixel-major) order
+# what the grouped op takes per direction: (attribute path of the forward direction's parameter, its suffix position)
+_FUSED = ("conv1d{}.weight", "conv1d{}.bias", "x_proj{}.weight", "dt_proj{}.weight", "dt_proj{}.bias", "A{}_log", "D{}")
+
+
+class _FusedView(torch.autograd.Function):
+    """The three directions' parameters of one kind as ONE (3, ...) tensor without a per-step cat / stack: `buf` is the
+    storage the three Parameters are views of (Mamba._fuse); the Parameters ride along only to receive the gradient, which
+    goes back as three views of the incoming one (no kernel on either way)."""
+
+    @staticmethod
+    def forward(ctx, buf, *params):
+        return buf.view_as(buf)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None,) + tuple(g[i] for i in range(g.shape[0]))
 
 
 class Mamba(nn.Module):
@@ -78,6 +94,42 @@ class Mamba(nn.Module):
             getattr(self, d_name)._no_weight_decay = True
         self.out_proj = nn.Linear(self.d_inner, d_model, bias=bias, **kw)
 
+    def _param(self, path):
+        obj = self
+        for name in path.split("."):
+            obj = getattr(obj, name)
+        return obj
+
+    def _fuse(self):
+        """Make the three directions' parameters of each kind views of one (3, ...) buffer (once; again after a `.to()` /
+        `.float()` has replaced the Parameters' storage).  Names, shapes and values of the Parameters do not change, so state
+        dicts, optimizers and DDP see what they saw; an optimizer that updates the Parameters in place updates the buffer."""
+        bufs = []
+        for kind in _FUSED:
+            ps = [self._param(kind.format(sfx)) for sfx in _DIRECTIONS]
+            if any(p is None for p in ps):
+                bufs.append(None)
+                continue
+            buf = torch.stack([p.data for p in ps])
+            for g, p in enumerate(ps):
+                p.data = buf[g]
+            bufs.append(buf)
+        self._fused = bufs
+
+    def _fused_params(self):
+        """-> [conv_w (3, D, 1, W), conv_b (3, D) | None, x_proj_w (3, R + 2N, D), dt_proj_w (3, D, R), dt_bias (3, D),
+        A_log (3, D, N), D (3, D)] with autograd edges to the per-direction Parameters."""
+        bufs = getattr(self, "_fused", None)
+        first, last = self.x_proj.weight, self.D_s
+        if bufs is None or bufs[2].data_ptr() != first.data_ptr() or bufs[2].device != first.device \
+                or bufs[6][2].data_ptr() != last.data_ptr() or bufs[2].dtype != first.dtype:
+            self._fuse()
+            bufs = self._fused
+        out = []
+        for kind, buf in zip(_FUSED, bufs):
+            out.append(None if buf is None else _FusedView.apply(buf, *(self._param(kind.format(sfx)) for sfx in _DIRECTIONS)))
+        return out
+
     def _inner(self, xz, sfx):
         conv, x_proj, dt_proj = (getattr(self, n + sfx) for n in ("conv1d", "x_proj", "dt_proj"))
         A = -torch.exp(getattr(self, f"A{sfx}_log").float())
@@ -107,16 +159,12 @@ class Mamba(nn.Module):
         # (n_groups = 3) per block instead of three of each (selective_scan_interface.MambaInnerGroupedFnNoOutProj).
         D = self.d_inner
         xz3 = stack_directions(xz, nf)                    # (B, 2, 3, D, L): identity / flip / frame interleave, one read
-        cat = lambda name: torch.cat([getattr(self, name + sfx) for sfx in _DIRECTIONS])
-        conv_w = torch.cat([getattr(self, "conv1d" + sfx).weight for sfx in _DIRECTIONS]).squeeze(1)
-        conv_b = (torch.cat([getattr(self, "conv1d" + sfx).bias for sfx in _DIRECTIONS])
-                  if self.conv1d.bias is not None else None)
-        x_proj_w = torch.stack([getattr(self, "x_proj" + sfx).weight for sfx in _DIRECTIONS])
-        dt_proj_w = torch.stack([getattr(self, "dt_proj" + sfx).weight for sfx in _DIRECTIONS])
-        dt_bias = torch.cat([getattr(self, "dt_proj" + sfx).bias for sfx in _DIRECTIONS]).float()
-        A = -torch.exp(torch.cat([getattr(self, f"A{sfx}_log") for sfx in _DIRECTIONS]).float())
-        o3 = mamba_inner_grouped_fn_no_out_proj(xz3, conv_w, conv_b, x_proj_w, dt_proj_w, A, cat("D").float(),
-                                                dt_bias, True).view(batch, 3, D, seqlen)
+        # the three directions' parameters as (3, ...) views of persistent fused storage: no per-step cat / stack
+        conv_w, conv_b, x_proj_w, dt_proj_w, dt_bias, A_log, Dp = self._fused_params()
+        A = -torch.exp(A_log.float()).view(3 * D, self.d_state)
+        o3 = mamba_inner_grouped_fn_no_out_proj(
+            xz3, conv_w.view(3 * D, self.d_conv), conv_b.view(3 * D) if conv_b is not None else None, x_proj_w, dt_proj_w,
+            A, Dp.float().view(3 * D), dt_bias.float().view(3 * D), True).view(batch, 3, D, seqlen)
         y = combine_directions(o3, nf).transpose(1, 2)    # (out + out_b.flip + out_s^-1) / 3, one write
         return F.linear(y, self.out_proj.weight, self.out_proj.bias)
 
