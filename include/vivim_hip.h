@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define VIVIM_ABI_VERSION 6
+#define VIVIM_ABI_VERSION 7
 
 typedef enum { VIVIM_F32 = 0, VIVIM_F16 = 1, VIVIM_BF16 = 2 } vivim_dtype_t;
 
@@ -143,7 +143,11 @@ typedef struct {
  * to x.transpose(1, 2).view(B, C, nf, H, W)); the reference has no kernel of its own there.
  * x, y: (batch, depth*height*width, channels), channels contiguous, token stride and batch stride free.
  * wt: (kd*9, channels) f32, TAP-major: wt[(kd*3 + kh)*3 + kw][c] = conv.weight[c][0][kd][kh][kw].
- * flip = 1 correlates with the reversed tap order: the input gradient of the same convolution. */
+ * flip = 1 correlates with the reversed tap order: the input gradient of the same convolution.
+ * act (ABI v7) fuses the Mlp's activation (modeling/vivim.py:99-106: act(dwconv(fc1(x))), act = nn.GELU, erf form) into
+ * the convolution's epilogue: 0 y = conv; 1 y = gelu(conv); 2 y = aux * gelu'(conv) -- the gradient with respect to the
+ * pre-activation, the convolution recomputed instead of stored (aux = the gradient of the activation's output, laid out
+ * like y).  act != 0 requires flip == 0. */
 typedef struct {
     int32_t batch, depth, height, width, channels;
     int32_t kd;                 /* 1 (2-D, 3x3) or 3 (3-D, 3x3x3) */
@@ -153,6 +157,9 @@ typedef struct {
     int64_t y_batch_stride, y_token_stride;
     const void *x, *wt, *bias;  /* bias (channels) f32 or NULL */
     void *y;
+    int32_t act, _pad1;
+    const void *aux;            /* act == 2: (batch, tokens, channels) itype, 16-byte aligned rows; else ignored */
+    int64_t aux_batch_stride, aux_token_stride;
 } vivim_dwconv_params;
 
 typedef struct {

@@ -73,6 +73,20 @@ def check_close(name, got, want, dtype, table, norm_tol=None, test=""):
     return e
 
 
+@pytest.fixture(autouse=True)
+def _poisoned_allocator(request):
+    """GPU tests start with the caching allocator's free blocks full of NaN / 3e38: a kernel or wrapper that reads memory
+    nobody wrote (an `empty` buffer whose columns are only partly filled, a halo before a row's first token) then fails its
+    parity check instead of passing whenever the allocator happens to hand out zeroed pages.  (It found the unwritten B / C
+    columns of dx_dbl in the fused op's constant-B/C backward -- a pattern inherited from the reference,
+    selective_scan_interface.py:262-271.)"""
+    if request.node.get_closest_marker("gpu") is not None and torch.cuda.is_available():
+        fill = float("nan") if (hash(request.node.name) & 1) else 3e38
+        junk = [torch.full((1 << k,), fill, device="cuda:0") for k in range(7, 25) for _ in range(2)]
+        del junk
+    yield
+
+
 @pytest.fixture(scope="session")
 def cuda():
     if not torch.cuda.is_available():

@@ -31,7 +31,7 @@ def test_struct_layouts_match():
                                 _lib.StateUpdateParams)):
         assert L.vivim_sizeof(which) == ctypes.sizeof(st)
     assert L.vivim_sizeof(99) == 0
-    assert L.vivim_abi_version() == 6
+    assert L.vivim_abi_version() == 7
     assert L.vivim_scan_chunk_len(_lib.F32) > 0 and L.vivim_scan_chunk_len(_lib.BF16) % 64 == 0
 
 

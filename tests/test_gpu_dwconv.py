@@ -49,6 +49,58 @@ def test_dwconv_matches_torch(dtype, B, D, H, W, C, k3, cuda):
     assert rel_err(got[3], b.grad) < (1e-4 if dtype == torch.float32 else 2e-3)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,D,H,W,C,k3", [(2, 5, 8, 8, 64, True), (1, 3, 7, 10, 24, True), (3, 1, 16, 16, 256, False),
+                                          (1, 8, 4, 4, 2048, True)])
+def test_dwconv_gelu_epilogue_matches_torch(dtype, B, D, H, W, C, k3, cuda):
+    """gelu(dwconv(x)) with the activation in the convolution's epilogue and the convolution recomputed in the backward
+    (vivim_dwconv_params.act = 1 / 2) against F.gelu(conv3d(x)) in fp32 (the Mlp's act(dwconv(fc1 x)), vivim.py:99-106)."""
+    from vivim_amd.dwconv import depthwise_conv_gelu_tokens, supported
+    g = torch.Generator().manual_seed(B * 100 + C + 1)
+    x = torch.randn(B, D * H * W, C, generator=g).to(dtype).to(cuda).requires_grad_(True)
+    wshape = (C, 1, 3, 3, 3) if k3 else (C, 1, 3, 3)
+    w = (torch.randn(*wshape, generator=g) * 0.3).to(cuda).requires_grad_(True)
+    b = torch.randn(C, generator=g).to(cuda).requires_grad_(True)
+    dy = torch.randn(B, D * H * W, C, generator=g).to(dtype).to(cuda)
+    if not supported(x, w):
+        pytest.skip("shape outside the kernel's alignment envelope (torch path is used)")
+    y = depthwise_conv_gelu_tokens(x, w, b, D, H, W)
+    y.backward(dy)
+    got = (y.detach(), x.grad.clone(), w.grad.clone(), b.grad.clone())
+    x.grad = w.grad = b.grad = None
+    yr = F.gelu(_ref(x, w, b, D, H, W))
+    yr.backward(dy.float())
+    tol = 2e-5 if dtype == torch.float32 else 1e-3
+    assert y.dtype == dtype and y.shape == x.shape
+    assert rel_err(got[0].float(), yr.detach().to(dtype).float()) < tol
+    # the gradient passes through a value the kernel rounds to the I/O dtype (dy * gelu'): 16-bit bound as for the plain op
+    assert rel_err(got[1].float(), x.grad.to(dtype).float()) < (tol if dtype == torch.float32 else 3e-3)
+    assert rel_err(got[2], w.grad) < (1e-4 if dtype == torch.float32 else 3e-3)
+    assert rel_err(got[3], b.grad) < (1e-4 if dtype == torch.float32 else 3e-3)
+
+
+def test_mlp_uses_the_fused_activation(cuda, monkeypatch):
+    """Mlp (vivim.py:86-108) with nn.GELU: fused path == dwconv followed by nn.GELU, forward and gradients."""
+    from modeling.vivim import Mlp
+    torch.manual_seed(0)
+    m = Mlp(64, 256).to(cuda)
+    x = torch.randn(2, 3 * 8 * 8, 64, device=cuda, requires_grad=True)
+
+    def run():
+        for p in m.parameters():
+            p.grad = None
+        x.grad = None
+        y = m(x, 3, 8, 8)
+        y.square().mean().backward()
+        return y.detach(), x.grad.clone(), [p.grad.clone() for p in m.parameters()]
+    y1, dx1, g1 = run()
+    monkeypatch.setenv("VIVIM_NO_DWCONV_GELU", "1")
+    y2, dx2, g2 = run()
+    assert rel_err(y1, y2) < 2e-5 and rel_err(dx1, dx2) < 1e-4
+    for a, c in zip(g1, g2):
+        assert rel_err(a, c) < 1e-4
+
+
 def test_dwconv_module_path_matches_conv3d_module(cuda):
     """DWConv (vivim.py:57-68) gives the same result through the HIP kernels as through nn.Conv3d."""
     from modeling.vivim import DWConv

@@ -68,6 +68,7 @@ class DwConvParams(ctypes.Structure):
         [(n, i32) for n in ("batch", "depth", "height", "width", "channels", "kd", "itype", "flip")]
         + [(n, i64) for n in ("x_batch_stride", "x_token_stride", "y_batch_stride", "y_token_stride")]
         + [(n, vp) for n in ("x", "wt", "bias", "y")]
+        + [("act", i32), ("_pad1", i32), ("aux", vp), ("aux_batch_stride", i64), ("aux_token_stride", i64)]
     )
 
 
@@ -149,7 +150,7 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = [ctypes.POINTER(st), vp]
             fn.restype = ctypes.c_int
-        if L.vivim_abi_version() != 6:
+        if L.vivim_abi_version() != 7:
             raise ImportError("libvivim_hip.so ABI version mismatch")
         for which, st in enumerate((SsmFwdParams, SsmBwdParams, ConvFwdParams, ConvBwdParams, DwConvParams,
                                     DwConvWgradParams, DirParams, ConvUpdateParams, StateUpdateParams)):

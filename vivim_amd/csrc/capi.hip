@@ -194,6 +194,10 @@ int vivim_dwconv_fwd(const vivim_dwconv_params* p, void* stream) {
     VCHECK(p->channels % cv == 0 && p->x_token_stride % cv == 0 && p->x_batch_stride % cv == 0 &&
            p->y_token_stride % cv == 0 && p->y_batch_stride % cv == 0);
     VCHECK((reinterpret_cast<uintptr_t>(p->x) & 15) == 0 && (reinterpret_cast<uintptr_t>(p->y) & 15) == 0);
+    VCHECK(p->act >= 0 && p->act <= 2 && (p->act == 0 || p->flip == 0));
+    if (p->act == 2)
+        VCHECK(p->aux && (reinterpret_cast<uintptr_t>(p->aux) & 15) == 0 && p->aux_token_stride % cv == 0 &&
+               p->aux_batch_stride % cv == 0);
     if (!vivim::dwconv_fwd_dispatch(*p, static_cast<hipStream_t>(stream)))
         return fail(VIVIM_ERR_UNSUPPORTED, "dwconv_fwd not implemented for input type %d", p->itype);
     return after_launch("dwconv_fwd");

@@ -18,7 +18,14 @@ namespace vivim {
 constexpr int kDwTW = 4;           // w positions per thread
 constexpr int kDwThreads = 256;
 
-template <typename T, int KD, bool FLIP>
+// erf-form GELU (torch.nn.GELU(), approximate = 'none') and its derivative, on the fp32 accumulator
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float v) {
+    return 0.5f * (1.0f + erff(v * 0.70710678118654752f)) + v * 0.39894228040143268f * __expf(-0.5f * v * v);
+}
+
+// ACT: 0 plain, 1 y = gelu(conv), 2 y = aux * gelu'(conv) (include/vivim_hip.h: vivim_dwconv_params.act)
+template <typename T, int KD, bool FLIP, int ACT = 0>
 __global__ void __launch_bounds__(kDwThreads) dwconv_fwd_kernel(const vivim_dwconv_params p) {
     constexpr int CV = 16 / (int)sizeof(T);           // channels per thread
     constexpr int CB = 8 * CV;                        // channels per block (8 lanes x CV = 128 B of one token)
@@ -76,6 +83,21 @@ __global__ void __launch_bounds__(kDwThreads) dwconv_fwd_kernel(const vivim_dwco
         }
     }
     const int64_t tok = ((int64_t)d * H + h) * W + w0;
+    if (ACT == 1) {
+#pragma unroll
+        for (int j = 0; j < TW; ++j)
+#pragma unroll
+            for (int v = 0; v < CV; ++v) acc[j][v] = gelu_erf(acc[j][v]);
+    } else if (ACT == 2) {
+        const T* __restrict__ aux = static_cast<const T*>(p.aux) + b * p.aux_batch_stride + c;
+#pragma unroll
+        for (int j = 0; j < TW; ++j) {
+            float gv[CV];
+            unpack(load_vec<T, CV>(aux + (tok + j) * p.aux_token_stride, w0 + j < W), gv);
+#pragma unroll
+            for (int v = 0; v < CV; ++v) acc[j][v] = gv[v] * gelu_erf_grad(acc[j][v]);
+        }
+    }
 #pragma unroll
     for (int j = 0; j < TW; ++j) store_vec<T, CV>(y + (tok + j) * p.y_token_stride, w0 + j < W, acc[j]);
 }
@@ -173,6 +195,16 @@ static bool dw_fwd(const vivim_dwconv_params& p, hipStream_t s) {
     const int wtiles = (p.width + kDwTW - 1) / kDwTW;
     const int ntiles = p.depth * p.height * wtiles;
     dim3 grid((ntiles + kDwThreads / 8 - 1) / (kDwThreads / 8), (p.channels + 8 * CV - 1) / (8 * CV), p.batch);
+    if (p.act == 1 || p.act == 2) {
+        if (p.kd == 3) {
+            if (p.act == 1) hipLaunchKernelGGL((dwconv_fwd_kernel<T, 3, false, 1>), grid, dim3(kDwThreads), 0, s, p);
+            else            hipLaunchKernelGGL((dwconv_fwd_kernel<T, 3, false, 2>), grid, dim3(kDwThreads), 0, s, p);
+        } else {
+            if (p.act == 1) hipLaunchKernelGGL((dwconv_fwd_kernel<T, 1, false, 1>), grid, dim3(kDwThreads), 0, s, p);
+            else            hipLaunchKernelGGL((dwconv_fwd_kernel<T, 1, false, 2>), grid, dim3(kDwThreads), 0, s, p);
+        }
+        return true;
+    }
     if (p.kd == 3) {
         if (p.flip) hipLaunchKernelGGL((dwconv_fwd_kernel<T, 3, true>), grid, dim3(kDwThreads), 0, s, p);
         else        hipLaunchKernelGGL((dwconv_fwd_kernel<T, 3, false>), grid, dim3(kDwThreads), 0, s, p);

@@ -154,16 +154,22 @@ class MambaInnerFnNoOutProj(torch.autograd.Function):
             ctx.delta_softplus, False)
         dx_dbl = torch.empty_like(x_dbl)
         dB_proj_bias = dC_proj_bias = None
+        # With a constant B (or C) the projection's B (C) columns feed nothing: their gradient is zero.  (The reference
+        # leaves them uninitialised, :262-271 -- harmless only while the allocator hands out zeroed memory.)
         if ctx.is_variable_B:
             dB = dB.squeeze(1).transpose(1, 2).reshape(batch * L, N)       # (b 1 N l) -> ((b l) N)
             dB_proj_bias = dB.sum(0) if not ctx.B_proj_bias_is_None else None
             dx_dbl[:, R:R + N] = dB
             dB = None
+        else:
+            dx_dbl[:, R:R + N].zero_()
         if ctx.is_variable_C:
             dC = dC.squeeze(1).transpose(1, 2).reshape(batch * L, N)
             dC_proj_bias = dC.sum(0) if not ctx.C_proj_bias_is_None else None
             dx_dbl[:, -N:] = dC
             dC = None
+        else:
+            dx_dbl[:, -N:].zero_()
         ddelta = ddelta.transpose(0, 1).reshape(d_inner, batch * L)        # (b d l) -> (d (b l))
         ddelta_proj_weight = ddelta @ x_dbl[:, :R]
         dx_dbl[:, :R] = ddelta.t() @ delta_proj_weight
@@ -430,6 +436,7 @@ class BiMambaInnerFn(torch.autograd.Function):
             dB = None
         else:
             dB = halves(dB2)
+            dx_dbl[:, R:R + N].zero_()                      # unused columns of the projection: zero gradient
         if ctx.is_variable_C:
             dC = fold(dC2).squeeze(1).transpose(1, 2).reshape(batch * L, N)
             dC_proj_bias = dC.sum(0) if ctx.C_proj_bias is not None else None
@@ -437,6 +444,7 @@ class BiMambaInnerFn(torch.autograd.Function):
             dC = None
         else:
             dC = halves(dC2)
+            dx_dbl[:, -N:].zero_()
         ddelta = fold(ddelta2).transpose(0, 1).reshape(d_inner, batch * L)
         ddelta_proj_weight = ddelta @ x_dbl[:, :R]
         dx_dbl[:, :R] = ddelta.t() @ delta_proj_weight

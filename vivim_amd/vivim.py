@@ -114,7 +114,14 @@ class Mlp(nn.Module):
         self.apply(_init_weights)
 
     def forward(self, x, nf, H, W):
-        x = self.drop(self.act(self.dwconv(self.fc1(x), nf, H, W)))
+        x = self.fc1(x)
+        conv = self.dwconv.dwconv
+        if isinstance(self.act, nn.GELU) and self.act.approximate == "none" and _dw.supported(x, conv.weight) \
+                and not os.environ.get("VIVIM_NO_DWCONV_GELU"):
+            # act(dwconv(.)) as one kernel: GELU in the convolution's epilogue (csrc/dwconv.hip, act = 1)
+            x = self.drop(_dw.depthwise_conv_gelu_tokens(x, conv.weight, conv.bias, nf, H, W))
+        else:
+            x = self.drop(self.act(self.dwconv(x, nf, H, W)))
         return self.drop(self.fc2(x))
 
 
