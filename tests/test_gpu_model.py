@@ -373,3 +373,33 @@ def test_lean_adamw_equals_torch_fused_adamw(cuda):
         ob.zero_grad(set_to_none=True)
     for a, b in zip(pa, pb):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_train_step_fp16_scaling_clipping_and_optimizer_state(cuda):
+    """The harness side of the reference's Trainer(precision=16, gradient_clip_val) (multiclass_training_folds.py:800-811):
+    fp16 autocast steps under the dynamic loss scale stay finite and move the loss, clipping bounds the update, and the lean
+    optimizer's state survives a state_dict round trip (same parameters after the same further step)."""
+    import copy
+    from vivim_amd.train_step import _SCALERS, build_model, make_optimizer, synthetic_batch, train_step
+    torch.manual_seed(21)
+    model = build_model(3, cuda, mamba_kwargs={"d_state": 16, "expand": 2}, drop_path_rate=0.0)
+    opt = make_optimizer(model)
+    clip, onehot = synthetic_batch(1, 3, 64, 3, cuda, 9)
+    losses = [float(train_step(model, opt, clip, onehot, 3, torch.float16, clip_grad_norm=1.0)) for _ in range(3)]
+    assert all(l == l and abs(l) < 1e4 for l in losses) and _SCALERS[id(opt)]["scale"] > 0
+    assert all(torch.isfinite(p).all() for p in model.parameters())
+    # state round trip: clone the model and the optimizer state, apply the SAME gradients to both (the kernels' fp32 atomics
+    # make two backward passes differ in the last bits, and Adam's m / sqrt(v) amplifies that): identical parameters after
+    model2 = copy.deepcopy(model)
+    opt2 = make_optimizer(model2)
+    opt2.load_state_dict(copy.deepcopy(opt.state_dict()))
+    g = torch.Generator(device="cpu").manual_seed(44)
+    for a, b in zip(model.parameters(), model2.parameters()):
+        if a.requires_grad:
+            a.grad = (1e-3 * torch.randn(a.shape, generator=g)).to(cuda)
+            b.grad = a.grad.clone()
+    opt.step()
+    opt2.step()
+    for (n, a), (_, b) in zip(model.named_parameters(), model2.named_parameters()):
+        assert torch.equal(a, b), n

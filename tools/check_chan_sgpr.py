@@ -13,16 +13,19 @@ def sgprs(line):
     out.update(int(x) for x in re.findall(r"\bs(\d+)\b", line))
     return out
 
-bad, kernels = [], 0
+bad, kernels, pairs = [], 0, {}
 name, in_asm, y_live, tag = None, False, False, None
 for ln, line in enumerate(open(sys.argv[1]), 1):
     m = re.match(r"^(_ZN5vivim19ssm_fwd_chan_kernel\S*):", line)
     if m:
         name, in_asm, y_live, kernels = m.group(1), False, False, kernels + 1
+        pairs[name] = {}
         continue
     if name is None:
         continue
-    if "s_endpgm" in line:
+    if re.match(r"^\.Lfunc_end|^\s+\.end_amdhsa_kernel|^[A-Za-z_][\w.$]*:\s*$", line):   # end of the function's text (an early
+        if y_live:                                                                        # s_endpgm does not end it)
+            bad.append((name, ln, "Y still live at the end of the kernel", line.strip()))
         name = None
         continue
     if "ASMSTART" in line:
@@ -39,6 +42,7 @@ for ln, line in enumerate(open(sys.argv[1]), 1):
         t = re.search(r"; CHAN (\w+)", line)
         if t:
             tag = t.group(1)
+            pairs[name][tag] = pairs[name].get(tag, 0) + 1
         continue
     code = line.split(";")[0]
     if not re.match(r"^\s+[sv]_|^\s+(ds|global|buffer|flat|scratch)_", code):
@@ -49,6 +53,9 @@ for ln, line in enumerate(open(sys.argv[1]), 1):
     if y_live and any(36 <= r <= 67 for r in regs):
         bad.append((name, ln, "touches Y (s36..s67) while it is live", line.strip()))
 assert kernels > 0, "no ssm_fwd_chan_kernel found in " + sys.argv[1]
+for k, tags in pairs.items():          # every block that makes Y live (lo_x) has the block that ends its life (hi_y), and vice versa
+    if tags.get("lo_x", 0) == 0 or tags.get("lo_x", 0) != tags.get("hi_y", 0) or tags.get("lo_y", 0) != tags.get("hi_x", 0):
+        bad.append((k, 0, "unbalanced token blocks", str(tags)))
 for b in bad[:20]:
     print("check-chan-sgpr: %s line %d: %s: %s" % b)
 if bad:

@@ -920,11 +920,11 @@ static void launch_bwd_fast(const vivim_ssm_bwd_params& p, const BwdPlan& plan, 
     }
     dim3 grid(bpg * f.n_groups, f.batch, sg.S);
     auto launch = [&](auto kernel) {
-        static size_t allowed = 65536;                  // per kernel instantiation (the lambda is instantiated per type)
-        if (smem > allowed) {
+        // The four <HAS_Z, DA_LDS> instantiations share one function-pointer TYPE, so a cache inside this generic lambda would
+        // be shared between them (and between devices): the attribute is simply set on every launch that needs it -- a
+        // host-side table write, no synchronisation.
+        if (smem > 65536)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            allowed = smem;
-        }
         hipLaunchKernelGGL(kernel, grid, block, smem, stream, p, sg);
     };
     if (f.z) { if (da_lds) launch(ssm_bwd_fast_kernel<T, K, true, W, true>); else launch(ssm_bwd_fast_kernel<T, K, true, W, false>); }

@@ -84,6 +84,26 @@ class LeanFusedAdamW:
         for p in self.params:
             p.grad = None
 
+    def state_dict(self):
+        """Checkpointable state: hyper-parameters and (exp_avg, exp_avg_sq, step) per parameter, in parameter order."""
+        out = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay, "state": []}
+        where = {id(p): (dev, i) for dev, ps in self.groups.items() for i, p in enumerate(ps)}
+        for p in self.params:
+            dev, i = where[id(p)]
+            m, v, t = self.state[dev]
+            out["state"].append({"exp_avg": m[i], "exp_avg_sq": v[i], "step": t[i]})
+        return out
+
+    def load_state_dict(self, sd):
+        assert len(sd["state"]) == len(self.params), "optimizer state does not match the parameter list"
+        self.lr, self.betas, self.eps, self.weight_decay = sd["lr"], tuple(sd["betas"]), sd["eps"], sd["weight_decay"]
+        where = {id(p): (dev, i) for dev, ps in self.groups.items() for i, p in enumerate(ps)}
+        with torch.no_grad():
+            for p, st in zip(self.params, sd["state"]):
+                dev, i = where[id(p)]
+                m, v, t = self.state[dev]
+                m[i].copy_(st["exp_avg"]); v[i].copy_(st["exp_avg_sq"]); t[i].copy_(st["step"])
+
     @torch.no_grad()
     def step(self):
         for dev, ps in self.groups.items():
@@ -127,8 +147,13 @@ def synthetic_batch(batch, clip_length, image_size, num_classes, device, seed):
     return clip.to(device), onehot.to(device)
 
 
-def train_step(model, optimizer, clip, onehot, num_classes, amp_dtype=torch.bfloat16):
-    """One fwd + loss + bwd + optimizer step; returns the detached loss."""
+_SCALERS = {}
+
+
+def train_step(model, optimizer, clip, onehot, num_classes, amp_dtype=torch.bfloat16, clip_grad_norm=None):
+    """One fwd + loss + bwd + optimizer step; returns the detached loss.  fp16 autocast runs under a GradScaler (the
+    reference trains with Trainer(precision=16), multiclass_training_folds.py:800-811; bf16 / fp32 need none);
+    `clip_grad_norm` (the reference's gradient_clip_val) clips the global gradient norm before the update."""
     if not model.training:                 # Module.train() walks all ~4000 submodules: 3 ms of host time when repeated per step
         model.train()
     with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype != torch.float32):
@@ -137,6 +162,24 @@ def train_step(model, optimizer, clip, onehot, num_classes, amp_dtype=torch.bflo
     target = onehot.argmax(dim=2).view(B * T, *onehot.shape[-2:])
     loss = recall_focused_loss(logits, target, num_classes)
     optimizer.zero_grad(set_to_none=True)
+    if amp_dtype == torch.float16:
+        sc = _SCALERS.setdefault(id(optimizer), {"scale": 65536.0, "good": 0})      # dynamic loss scale, GradScaler's policy
+        (loss * sc["scale"]).backward()
+        params = [p for p in model.parameters() if p.grad is not None]
+        torch._foreach_mul_([p.grad for p in params], 1.0 / sc["scale"])
+        finite = bool(torch.stack([torch.isfinite(p.grad).all() for p in params]).all())   # one host sync per step
+        if finite:
+            if clip_grad_norm is not None:
+                torch.nn.utils.clip_grad_norm_(params, clip_grad_norm)
+            optimizer.step()
+            sc["good"] += 1
+            if sc["good"] == 2000:
+                sc["scale"], sc["good"] = sc["scale"] * 2.0, 0
+        else:                                                # skip the update, halve the scale
+            sc["scale"], sc["good"] = sc["scale"] * 0.5, 0
+        return loss.detach()
     loss.backward()
+    if clip_grad_norm is not None:
+        torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], clip_grad_norm)
     optimizer.step()
     return loss.detach()
