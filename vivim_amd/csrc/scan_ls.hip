@@ -1113,8 +1113,9 @@ static size_t ls_bwd_smem(int W, int NS) {
     // per wave: 8 KB of dB / dC slots + the channels' state (4 floats per lane and channel; dstate 32 / 64: + the rebuilt
     // states at the inner tile boundaries of a checkpoint block) + the D / bias table: 50.1 KB for 4 waves at dstate 16
     const int RPS = NS / 16, SPW = 4 / RPS;
+    static const size_t pad = getenv("VIVIM_LS_SMEM_PAD") ? (size_t)atoi(getenv("VIVIM_LS_SMEM_PAD")) : 0;   // occupancy experiments
     return ((size_t)W * SPW * 2 * NS * 16 + (size_t)W * kLsCPR * (4 + RPS - 1) * kWave + (size_t)W * kLsCPR * 8) * sizeof(float) +
-           (size_t)2 * NS * 16 * 4;                            // + the staged B / C rows of one tile (sized for fp32)
+           (size_t)2 * NS * 16 * 4 + pad;                      // + the staged B / C rows of one tile (sized for fp32)
 }
 template <typename T> static int ls_bwd_blocks_per_cu_t(const vivim_ssm_fwd_params& f, int W) {
     const size_t smem = ls_bwd_smem(W, f.dstate);
