@@ -13,6 +13,25 @@ namespace vivim {
 
 constexpr int kConvThreads = 256;
 
+// Which (channel, tile) a wave works on.  Long rows: the workgroup's four waves take four consecutive 64*E-token tiles of
+// the row blockIdx.y.  PACK (rows shorter than four tiles -- Vivim's stages 2 and 3: 1280 and 320 tokens): the waves of
+// the launch are numbered through (channel, tile) pairs, so a 320-token row is one wave instead of a 256-thread
+// workgroup with 216 idle lanes; a wave past the last channel has nothing to do.
+template <bool PACK, int E>
+__device__ __forceinline__ bool conv_tile(int L, int dim, int& c, int& t0) {
+    const int lane = threadIdx.x & 63;
+    if (!PACK) {
+        c = blockIdx.y;
+        t0 = (blockIdx.x * kConvThreads + threadIdx.x) * E;
+        return true;
+    }
+    const int tpr = (L + kWave * E - 1) / (kWave * E);
+    const int wid = blockIdx.x * (kConvThreads / kWave) + (threadIdx.x >> 6);
+    c = __builtin_amdgcn_readfirstlane(wid / tpr);
+    t0 = ((wid - c * tpr) * kWave + lane) * E;
+    return c < dim;
+}
+
 // taps are right-aligned into 4 slots so one code path serves width 2..4:
 //   out[t] = bias + sum_{j<4} w4[j] * x[t - 3 + j],   w4[j] = weight[j - (4 - W)] (0 for j < 4 - W)
 template <typename WT>
@@ -24,12 +43,13 @@ __device__ __forceinline__ void load_taps(const WT* w, int64_t wstride, int widt
     }
 }
 
-template <typename T, typename WT, int E>
+template <typename T, typename WT, int E, bool PACK>
 __global__ void __launch_bounds__(kConvThreads) conv1d_fwd_kernel(const vivim_conv_fwd_params p) {
     const int lane = threadIdx.x & 63;
-    const int c = blockIdx.y, b = blockIdx.z;
+    const int b = blockIdx.z;
     const int L = p.seqlen;
-    const int t0 = (blockIdx.x * kConvThreads + threadIdx.x) * E;
+    int c, t0;
+    if (!conv_tile<PACK, E>(L, p.dim, c, t0)) return;           // whole waves only; no barrier in this kernel
     const T* __restrict__ x = static_cast<const T*>(p.x) + b * p.x_batch_stride + c * p.x_c_stride;
     T* __restrict__ out = static_cast<T*>(p.out) + b * p.out_batch_stride + c * p.out_c_stride;
 
@@ -69,13 +89,14 @@ __global__ void __launch_bounds__(kConvThreads) conv1d_fwd_kernel(const vivim_co
 //   g[t]   = dout[t] * silu'(pre[t])            (pre recomputed from x, bwd.cu:163-175)
 //   dx[s]  = sum_j w4[j] * g[s + 3 - j]
 //   dw4[j] = sum_t g[t] * x[t - 3 + j],  dbias = sum_t g[t]     (own tokens only, then reduced)
-template <typename T, typename WT, int E>
+template <typename T, typename WT, int E, bool PACK>
 __global__ void __launch_bounds__(kConvThreads) conv1d_bwd_kernel(const vivim_conv_bwd_params p) {
     const vivim_conv_fwd_params& f = p.f;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.y, b = blockIdx.z;
+    const int b = blockIdx.z;
     const int L = f.seqlen;
-    const int t0 = (blockIdx.x * kConvThreads + threadIdx.x) * E;
+    int c, t0;
+    if (!conv_tile<PACK, E>(L, f.dim, c, t0)) return;           // PACK only (whole waves; the PACK path has no barrier)
     const T* __restrict__ x = static_cast<const T*>(f.x) + b * f.x_batch_stride + c * f.x_c_stride;
     const T* __restrict__ dout = static_cast<const T*>(p.dout) + b * p.dout_batch_stride + c * p.dout_c_stride;
     T* __restrict__ dx = static_cast<T*>(p.dx) + b * p.dx_batch_stride + c * p.dx_c_stride;
@@ -141,6 +162,22 @@ __global__ void __launch_bounds__(kConvThreads) conv1d_bwd_kernel(const vivim_co
         for (int i = 0; i < 4; ++i) red[i] = fmaf(g[k], X[k + i], red[i]);
         red[4] += g[k];
     }
+    if (PACK) {                                   // the waves of a workgroup hold different channels: one wave, five atomics
+        float mine = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const float s = wave_sum(red[i]);
+            if (lane == i) mine = s;
+        }
+        if (lane < 4) {
+            const int src = lane - (4 - f.width);
+            if (src >= 0)
+                atomicAdd(static_cast<float*>(p.dweight) + c * p.dweight_c_stride + src * p.dweight_width_stride, mine);
+        } else if (lane == 4 && p.dbias) {
+            atomicAdd(static_cast<float*>(p.dbias) + c, mine);
+        }
+        return;
+    }
     __shared__ float part[kConvThreads / kWave][5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
@@ -165,14 +202,26 @@ __global__ void __launch_bounds__(kConvThreads) conv1d_bwd_kernel(const vivim_co
 template <typename T, typename WT>
 static void launch_conv_fwd(const vivim_conv_fwd_params& p, hipStream_t stream) {
     constexpr int E = 16 / sizeof(T);   // one 16-byte access per lane
+    const int tpr = (p.seqlen + kWave * E - 1) / (kWave * E);          // 64*E-token tiles per row
+    if (tpr < kConvThreads / kWave) {                                   // short rows: waves numbered through (channel, tile)
+        const int waves = p.dim * tpr, wpb = kConvThreads / kWave;
+        hipLaunchKernelGGL((conv1d_fwd_kernel<T, WT, E, true>), dim3((waves + wpb - 1) / wpb, 1, p.batch), dim3(kConvThreads), 0, stream, p);
+        return;
+    }
     dim3 grid((p.seqlen + kConvThreads * E - 1) / (kConvThreads * E), p.dim, p.batch);
-    hipLaunchKernelGGL((conv1d_fwd_kernel<T, WT, E>), grid, dim3(kConvThreads), 0, stream, p);
+    hipLaunchKernelGGL((conv1d_fwd_kernel<T, WT, E, false>), grid, dim3(kConvThreads), 0, stream, p);
 }
 template <typename T, typename WT>
 static void launch_conv_bwd(const vivim_conv_bwd_params& p, hipStream_t stream) {
     constexpr int E = 16 / sizeof(T);
+    const int tpr = (p.f.seqlen + kWave * E - 1) / (kWave * E);
+    if (tpr < kConvThreads / kWave) {
+        const int waves = p.f.dim * tpr, wpb = kConvThreads / kWave;
+        hipLaunchKernelGGL((conv1d_bwd_kernel<T, WT, E, true>), dim3((waves + wpb - 1) / wpb, 1, p.f.batch), dim3(kConvThreads), 0, stream, p);
+        return;
+    }
     dim3 grid((p.f.seqlen + kConvThreads * E - 1) / (kConvThreads * E), p.f.dim, p.f.batch);
-    hipLaunchKernelGGL((conv1d_bwd_kernel<T, WT, E>), grid, dim3(kConvThreads), 0, stream, p);
+    hipLaunchKernelGGL((conv1d_bwd_kernel<T, WT, E, false>), grid, dim3(kConvThreads), 0, stream, p);
 }
 
 template <typename T>
