@@ -1,43 +1,28 @@
-#!/usr/bin/env python3
-"""Host-side profile of the benchmark's train step (cProfile, main thread: forward + loss + optimizer; the
-autograd engine runs custom backward functions on its own thread, which cProfile does not see).
-    python tools/host_profile.py [steps]  ->  top functions by own time / cumulative time."""
-import cProfile, io, os, pstats, sys, time
+"""Where the host time of a train step goes (the step is host-paced): cProfile over a few steps, the vivim_amd wrappers and the
+top of the list.   python tools/host_profile.py [steps]"""
+import cProfile, io, os, pstats, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-from vivim_amd.train_step import build_model, make_optimizer, synthetic_batch, train_step
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vivim_amd import train_step as ts
 
-steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-dev = torch.device("cuda", 0)
-torch.manual_seed(42)
-model = build_model(3, dev, mamba_kwargs={"d_state": 16, "expand": 2})
-clip, onehot = synthetic_batch(3, 5, 256, 3, dev, 42)
-opt = make_optimizer(model)
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+model = ts.build_model(3, dev)
+opt = ts.make_optimizer(model)
+clip, onehot = ts.synthetic_batch(3, 5, 256, 3, dev, 0)
 for _ in range(3):
-    train_step(model, opt, clip, onehot, 3, torch.bfloat16)
+    ts.train_step(model, opt, clip, onehot, 3, torch.bfloat16)
 torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(steps):
-    train_step(model, opt, clip, onehot, 3, torch.bfloat16)
-torch.cuda.synchronize()
-print(f"unprofiled: {(time.perf_counter() - t0) / steps * 1e3:.1f} ms/step")
-# forward only, to split host time between forward and backward
-with torch.no_grad():
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(steps):
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            model(clip)
-    torch.cuda.synchronize()
-print(f"forward only (no_grad): {(time.perf_counter() - t0) / steps * 1e3:.1f} ms/step")
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(steps):
-    train_step(model, opt, clip, onehot, 3, torch.bfloat16)
+    ts.train_step(model, opt, clip, onehot, 3, torch.bfloat16)
 torch.cuda.synchronize()
 pr.disable()
-for key in ("tottime", "cumulative"):
+for key, pat in (("cumulative", "vivim_amd"), ("tottime", None)):
     s = io.StringIO()
-    pstats.Stats(pr, stream=s).strip_dirs().sort_stats(key).print_stats(28)
-    print(f"==== by {key} ({steps} steps) ====")
+    st = pstats.Stats(pr, stream=s).sort_stats(key)
+    st.print_stats(pat, 30) if pat else st.print_stats(25)
+    print(f"==== per {steps} steps, sorted by {key}" + (f", filter {pat}" if pat else ""))
     print("\n".join(l for l in s.getvalue().splitlines() if l.strip())[:6000])

@@ -29,18 +29,23 @@ _DIRECTIONS = ("", "_b", "_s")     # forward in time, backward in time, spatial 
 _FUSED = ("conv1d{}.weight", "conv1d{}.bias", "x_proj{}.weight", "dt_proj{}.weight", "dt_proj{}.bias", "A{}_log", "D{}")
 
 
-class _FusedView(torch.autograd.Function):
-    """The three directions' parameters of one kind as ONE (3, ...) tensor without a per-step cat / stack: `buf` is the
-    storage the three Parameters are views of (Mamba._fuse); the Parameters ride along only to receive the gradient, which
-    goes back as three views of the incoming one (no kernel on either way)."""
+class _FusedViews(torch.autograd.Function):
+    """The three directions' parameters of each kind as ONE (3, ...) tensor without a per-step cat / stack: `bufs` are the
+    storages the Parameters are views of (Mamba._fuse); the Parameters ride along only to receive the gradients, which go
+    back as three views of each incoming one.  One node for all kinds (an `apply` costs ~15 us of host time), no kernel
+    on either way."""
 
     @staticmethod
-    def forward(ctx, buf, *params):
-        return buf.view_as(buf)
+    def forward(ctx, nb, *args):
+        ctx.nb = nb
+        return tuple(b.view_as(b) for b in args[:nb])
 
     @staticmethod
-    def backward(ctx, g):
-        return (None,) + tuple(g[i] for i in range(g.shape[0]))
+    def backward(ctx, *gs):
+        out = [None] * (1 + ctx.nb)
+        for g in gs:
+            out += [None, None, None] if g is None else [g[0], g[1], g[2]]
+        return tuple(out)
 
 
 class Mamba(nn.Module):
@@ -94,41 +99,45 @@ class Mamba(nn.Module):
             getattr(self, d_name)._no_weight_decay = True
         self.out_proj = nn.Linear(self.d_inner, d_model, bias=bias, **kw)
 
-    def _param(self, path):
-        obj = self
-        for name in path.split("."):
-            obj = getattr(obj, name)
-        return obj
-
     def _fuse(self):
         """Make the three directions' parameters of each kind views of one (3, ...) buffer (once; again after a `.to()` /
         `.float()` has replaced the Parameters' storage).  Names, shapes and values of the Parameters do not change, so state
         dicts, optimizers and DDP see what they saw; an optimizer that updates the Parameters in place updates the buffer."""
-        bufs = []
+        def param(path):
+            obj = self
+            for name in path.split("."):
+                obj = getattr(obj, name)
+            return obj
+        bufs, groups = [], []
         for kind in _FUSED:
-            ps = [self._param(kind.format(sfx)) for sfx in _DIRECTIONS]
+            ps = [param(kind.format(sfx)) for sfx in _DIRECTIONS]
             if any(p is None for p in ps):
                 bufs.append(None)
+                groups.append(None)
                 continue
             buf = torch.stack([p.data for p in ps])
             for g, p in enumerate(ps):
                 p.data = buf[g]
             bufs.append(buf)
+            groups.append(ps)
         self._fused = bufs
+        self._fused_live = [b for b in bufs if b is not None]
+        self._fused_args = self._fused_live + [p for ps in groups if ps is not None for p in ps]
+        self._fused_check = (groups[2][0], groups[6][2])     # first and last Parameter fused: x_proj.weight, D_s
 
     def _fused_params(self):
         """-> [conv_w (3, D, 1, W), conv_b (3, D) | None, x_proj_w (3, R + 2N, D), dt_proj_w (3, D, R), dt_bias (3, D),
         A_log (3, D, N), D (3, D)] with autograd edges to the per-direction Parameters."""
         bufs = getattr(self, "_fused", None)
-        first, last = self.x_proj.weight, self.D_s
-        if bufs is None or bufs[2].data_ptr() != first.data_ptr() or bufs[2].device != first.device \
-                or bufs[6][2].data_ptr() != last.data_ptr() or bufs[2].dtype != first.dtype:
+        if bufs is not None:
+            first, last = self._fused_check
+            ok = (bufs[2].data_ptr() == first.data_ptr() and bufs[6][2].data_ptr() == last.data_ptr()
+                  and bufs[2].dtype == first.dtype and first is self.x_proj.weight)
+        if bufs is None or not ok:
             self._fuse()
             bufs = self._fused
-        out = []
-        for kind, buf in zip(_FUSED, bufs):
-            out.append(None if buf is None else _FusedView.apply(buf, *(self._param(kind.format(sfx)) for sfx in _DIRECTIONS)))
-        return out
+        views = iter(_FusedViews.apply(len(self._fused_live), *self._fused_args))
+        return [None if b is None else next(views) for b in bufs]
 
     def _inner(self, xz, sfx):
         conv, x_proj, dt_proj = (getattr(self, n + sfx) for n in ("conv1d", "x_proj", "dt_proj"))
