@@ -1,6 +1,6 @@
 #!/bin/bash
 # One measurement pass on the GPU box: full bench line, kernel micro-benchmarks, rocprofv3 kernel stats of bench.py and
-# the three PMC passes (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU: one counter per pass, kernel trace only).  Everything lands
+# (the three PMC passes are tools/pmc_round.sh: run it after this one, in the same call, joined with &&).  Everything lands
 # under gpurun_out/ with the given tag; copy what is to be kept to profiles/.
 #   gpurun --timeout 1190 -- 'bash tools/measure_round.sh r02_v1'
 # Stops at the first failing GPU step (set -e): no GPU step is started after one that timed out.
@@ -20,13 +20,9 @@ timeout -k 10 400 python bench.py > "$out/bench_$tag.json" 2> "$out/bench_$tag.e
 } > "$out/kbench_$tag.log"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_$tag" -o bench -- python3 "$root/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-by-config > /dev/null 2>&1
-for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$out/pmc_$c" -o b -- python3 "$root/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-by-config > /dev/null 2>&1
-done
 cd "$root"
 python tools/prof_summary.py "$out/prof_$tag" "$out/${tag}_bench_kernel_stats.csv" 60
-python tools/pmc_bench_traffic.py "$out/pmc_FETCH_SIZE" "$out/pmc_WRITE_SIZE" "$out/pmc_SQ_INSTS_VALU" "$out/${tag}_bench_pmc_traffic.json" > /dev/null
-rm -rf "$out/prof_$tag" "$out/pmc_FETCH_SIZE" "$out/pmc_WRITE_SIZE" "$out/pmc_SQ_INSTS_VALU"
+rm -rf "$out/prof_$tag"
 python - "$out/bench_$tag.json" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
