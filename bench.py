@@ -156,7 +156,7 @@ def pmc_record(entry_point):
         return None, None, None, False
 
 
-VALU_PEAK_GINST = 1024 * 2.4 / 2      # wave-instructions per ns: 1024 SIMD-32 x 2.4 GHz, one wave64 instruction per 2 cycles
+VALU_PEAK_GINST = 1024 * 2.4 / 2      # G wave-instructions per s: 1024 SIMD-32 x 2.4 GHz, one wave64 instruction per 2 cycles
 
 
 def roofline_by_config(dev, iters=4):
@@ -271,8 +271,8 @@ def main():
         co = None
         if valu_insts and not stale:
             co = {"kind": "valu", "wave_insts_per_launch": int(valu_insts),
-                  "achieved_Ginst_per_s": round(valu_insts / avg_s / 1e9, 1), "peak_Ginst_per_s": round(VALU_PEAK_GINST * 1e3, 1),
-                  "frac": round(valu_insts / avg_s / 1e9 / (VALU_PEAK_GINST * 1e3), 4),
+                  "achieved_Ginst_per_s": round(valu_insts / avg_s / 1e9, 1), "peak_Ginst_per_s": round(VALU_PEAK_GINST, 1),
+                  "frac": round(valu_insts / avg_s / 1e9 / VALU_PEAK_GINST, 4),
                   "note": "SQ_INSTS_VALU per launch (committed PMC pass) / live launch time; the larger of roofline.frac and "
                           "this one names the bound"}
         kernels = {k.replace("vivim_", ""): {"launches": v[2], "total_ms": round(v[1] * 1e3, 3),
