@@ -423,7 +423,8 @@ static void fwd_chan_segmentation(const vivim_ssm_fwd_params& f, int tt, int& S,
     // 2048 waves: swept 512 ... 8192 on the grouped cfg-2 shapes (309/144/106/64 us at 2048; 377/198/130/68 at 1024;
     // 320/167/125/70 at 4096); again with the packed token update: 293/146/101/69 at 1536, 283/141/104/70 at 2048,
     // 300/164/115/70 at 3072, 304/165/124/70 at 4096
-    int64_t want = (2048 + waves - 1) / waves;
+    static const int target = getenv("VIVIM_CHAN_WAVES") ? atoi(getenv("VIVIM_CHAN_WAVES")) : 2048;   // (sweeps)
+    int64_t want = (target + waves - 1) / waves;
     if (want > ntiles) want = ntiles;
     if (want > 512) want = 512;       // the carry kernel keeps a whole chain in LDS: 512 * 17 * 4 = 34 KB
     if (want < 1) want = 1;
