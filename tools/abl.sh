@@ -5,6 +5,23 @@ set -e
 cd "$(dirname "$0")/../vivim_amd/csrc"
 mode=$1; shift
 mkdir -p abl
+if [ "$mode" = chanbuild ]; then     # lanes=channels forward ablations (-DCH_ABL=n)
+  for n in "$@"; do
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -DCH_ABL=$n -c scan_fwd_chan.hip -o abl/scan_fwd_chan_$n.o 2> abl/scan_fwd_chan_$n.res
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o abl/libvivim_chabl_$n.so capi.o conv1d.o conv1d_cl.o scan_fwd.o abl/scan_fwd_chan_$n.o scan_ls.o scan_bwd.o dwconv.o dirmap.o update.o
+    echo "built chan abl $n"
+  done
+  exit 0
+fi
+if [ "$mode" = chanrun ]; then
+  cd ../..
+  for n in "$@"; do
+    echo "== CH_ABL=$n"
+    VIVIM_LIB=$PWD/vivim_amd/csrc/abl/libvivim_chabl_$n.so python tools/kbench.py --config 3 --stages 0 --kernels sf --iters 6 | grep stage
+    VIVIM_LIB=$PWD/vivim_amd/csrc/abl/libvivim_chabl_$n.so python tools/kbench.py --config 2 --groups 3 --stages 0 --kernels sf --iters 20 | grep stage
+  done
+  exit 0
+fi
 if [ "$mode" = build ]; then
   for n in "$@"; do
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -DLS_ABL=$n -Rpass-analysis=kernel-resource-usage -c scan_ls.hip -o abl/scan_ls_$n.o 2> abl/scan_ls_$n.res

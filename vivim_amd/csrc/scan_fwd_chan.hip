@@ -25,9 +25,20 @@
 
 namespace vivim {
 
+// CH_ABL: timing experiments (tools/abl.sh chan): 1 no scalar B / C loads, 2 no tile loads, 3 no tile stores, 4 no exp -- results
+// are wrong for any value but 0; never set in the product build.
+#ifndef CH_ABL
+#define CH_ABL 0
+#endif
+constexpr int kChAbl = CH_ABL;
 constexpr int kChN = 16;           // states (compile time: they live in registers)
 constexpr int kChWaves = 2;        // independent waves per workgroup
-constexpr int kChTT = 16;          // tokens per tile (16-bit: 32-byte row pieces, 9 KB of LDS per wave; fp32: 64-byte, 15 KB)
+// Tokens per tile: a tile row is 64 bytes for every I/O type (16 fp32 / 32 16-bit tokens; 15 KB of LDS per wave with three
+// resident streams).  With 32-byte pieces (16 tokens of bf16, the first version) a 128-byte line of a row is fetched for
+// four separate tiles, microseconds apart, with 2048 waves x 64 rows x 3 streams of such lines in flight -- far more than
+// the L2s hold: rocprofv3 counted 1.17 GB of HBM traffic per launch against 0.25 GB algorithmic at cfg 2's grouped stage 0,
+// i.e. 4.1 TB/s in 283 us: the launch was bound by its own over-fetch (profiles/r02_hbm_counters_per_kernel.txt).
+template <typename T> struct ChTile { static constexpr int TT = 64 / (int)sizeof(T); };
 
 int scan_ckpt_len(const vivim_ssm_fwd_params&);                          // scan_fwd.hip
 
@@ -109,8 +120,7 @@ typedef float cf2 __attribute__((ext_vector_type(2)));
 #define CHP_PAIR(j, BP, CP)                                                                        \
     {                                                                                              \
         cf2 t = dlp * ap[j];                                                                       \
-        t.x = fast_exp2(t.x);                                                                      \
-        t.y = fast_exp2(t.y);                                                                      \
+        if (kChAbl != 4) { t.x = fast_exp2(t.x); t.y = fast_exp2(t.y); }                           \
         cf2 u;                                                                                     \
         asm volatile("v_pk_mul_f32 %0, " BP ", %1" : "=v"(u) : "v"(wp));                           \
         hp[j] = __builtin_elementwise_fma(t, hp[j], u);                                            \
@@ -128,7 +138,8 @@ typedef float cf2 __attribute__((ext_vector_type(2)));
 template <int PASS>
 __device__ __forceinline__ void chan_token_x(cf2* hp, const cf2* ap, float dl, float w, cf2& y2, const float* next) {
     const cf2 dlp = {dl, dl}, wp = {w, w};
-    if (PASS == 2) asm volatile("; CHAN lo_x\n\t" CH_LOAD_Y2 : : [ptr] "s"(next) : CH_CLOB_Y);
+    if (kChAbl == 1) asm volatile("; CHAN lo_x\n\t" : : [ptr] "s"(next) : CH_CLOB_Y);
+    else if (PASS == 2) asm volatile("; CHAN lo_x\n\t" CH_LOAD_Y2 : : [ptr] "s"(next) : CH_CLOB_Y);
     else           asm volatile("; CHAN lo_x\n\t" CH_LOAD_Y1 : : [ptr] "s"(next) : CH_CLOB_Y);
     CHP_PAIR(0, "s[68:69]", "s[76:77]") CHP_PAIR(1, "s[70:71]", "s[78:79]")
     CHP_PAIR(2, "s[72:73]", "s[80:81]") CHP_PAIR(3, "s[74:75]", "s[82:83]")
@@ -140,7 +151,8 @@ __device__ __forceinline__ void chan_token_x(cf2* hp, const cf2* ap, float dl, f
 template <int PASS>
 __device__ __forceinline__ void chan_token_y(cf2* hp, const cf2* ap, float dl, float w, cf2& y2, const float* next) {
     const cf2 dlp = {dl, dl}, wp = {w, w};
-    if (PASS == 2) asm volatile("; CHAN lo_y\n\t" CH_LOAD_X2 : : [ptr] "s"(next) : CH_CLOB_X);
+    if (kChAbl == 1) asm volatile("; CHAN lo_y\n\t" : : [ptr] "s"(next) : CH_CLOB_X);
+    else if (PASS == 2) asm volatile("; CHAN lo_y\n\t" CH_LOAD_X2 : : [ptr] "s"(next) : CH_CLOB_X);
     else           asm volatile("; CHAN lo_y\n\t" CH_LOAD_X1 : : [ptr] "s"(next) : CH_CLOB_X);
     CHP_PAIR(0, "s[36:37]", "s[44:45]") CHP_PAIR(1, "s[38:39]", "s[46:47]")
     CHP_PAIR(2, "s[40:41]", "s[48:49]") CHP_PAIR(3, "s[42:43]", "s[50:51]")
@@ -172,7 +184,7 @@ __global__ void __launch_bounds__(kChWaves * kWave) __attribute__((amdgpu_num_sg
 ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
     constexpr int N = kChN;
     constexpr int EPV = 16 / (int)sizeof(T);          // elements per 16-byte vector
-    constexpr int TT = kChTT;                         // tokens per tile
+    constexpr int TT = ChTile<T>::TT;                 // tokens per tile
     constexpr int RB = TT * (int)sizeof(T);           // bytes of a row inside a tile (32 for 16-bit, 64 for fp32)
     constexpr int LPR = RB / 16;                      // lanes (16-byte columns) per row
     constexpr int RPI = kWave / LPR;                  // rows per cooperative load/store instruction
@@ -238,6 +250,7 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
     union tile_regs { RawK<T, EPV> r; v4 v; };
     tile_regs nu[NIO], nd[NIO], nz[NIO];
     auto issue_tile_loads = [&](int tile) {
+        if (kChAbl == 2 && tile > tile_lo) return;
         kparams_t q = fresh_params();
         // Unconditional loads (countable vmcnt: a load under a branch would make the next wait a full drain); columns past
         // the end are clamped onto the row's last vector -- their tokens are never processed (blocks stop at L, the
@@ -335,7 +348,7 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
             }
         }
         wave_lds_fence();
-        if (PASS == 2) {                               // LDS -> global, coalesced
+        if (PASS == 2 && kChAbl != 3) {                // LDS -> global, coalesced
             kparams_t q = fresh_params();
             const int t = t0 + io_col * EPV;
             if (t < L) {
@@ -447,9 +460,10 @@ static bool fwd_chan_eligible(const vivim_ssm_fwd_params& p, bool shape_only = f
     if (tune != 5) {
         if (tune != 0) return false;
         const int64_t cols = (int64_t)p.batch * (p.dim / kWave);
-        // short checkpoint rows (scan_ckpt_len): the alternative is the lanes = states forward, which wins below ~250 k
-        // wave-tokens (cfg 2 grouped stages 1-3: 144 / 93 / 51 us against 151 / 109 / 61; cfg 3 stage 2, 410 k: 361 against 302)
-        const int64_t least = scan_ckpt_len(p) < kChunk ? 250000 : 110000;
+        // short checkpoint rows (scan_ckpt_len): the alternative is the lanes = states forward, which wins below ~150 k
+        // wave-tokens (cfg 2 grouped stages 1-3, 184 k / 115 k / 46 k: 150 / 98 / 51 us against 137 / 100 / 59 with 64-byte
+        // tile rows; cfg 3 stage 2, 410 k: 361 against 302)
+        const int64_t least = scan_ckpt_len(p) < kChunk ? 150000 : 110000;
         if (cols < 8 || cols * p.seqlen < least) return false;
     }
     const int64_t epv = p.itype == VIVIM_F32 ? 4 : 8;
@@ -478,12 +492,12 @@ size_t fwd_chan_workspace_bytes(const vivim_ssm_fwd_params& f) {
     if (!fwd_chan_eligible(f, true)) return 0;
     int S, seg_tiles, Lpad;
     size_t bc;
-    return fwd_chan_layout(f, kChTT, S, seg_tiles, Lpad, bc);
+    return fwd_chan_layout(f, f.itype == VIVIM_F32 ? ChTile<float>::TT : ChTile<bf16_t>::TT, S, seg_tiles, Lpad, bc);
 }
 
 template <typename T>
 static bool launch_fwd_chan(const vivim_ssm_fwd_params& p, hipStream_t stream) {
-    constexpr int TT = kChTT;
+    constexpr int TT = ChTile<T>::TT;
     int S, seg_tiles, Lpad;
     size_t bc_floats;
     const size_t need = fwd_chan_layout(p, TT, S, seg_tiles, Lpad, bc_floats);
