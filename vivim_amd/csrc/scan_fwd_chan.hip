@@ -33,12 +33,16 @@ namespace vivim {
 constexpr int kChAbl = CH_ABL;
 constexpr int kChN = 16;           // states (compile time: they live in registers)
 constexpr int kChWaves = 2;        // independent waves per workgroup
-// Tokens per tile: a tile row is 64 bytes for every I/O type (16 fp32 / 32 16-bit tokens; 15 KB of LDS per wave with three
-// resident streams).  With 32-byte pieces (16 tokens of bf16, the first version) a 128-byte line of a row is fetched for
-// four separate tiles, microseconds apart, with 2048 waves x 64 rows x 3 streams of such lines in flight -- far more than
-// the L2s hold: rocprofv3 counted 1.17 GB of HBM traffic per launch against 0.25 GB algorithmic at cfg 2's grouped stage 0,
-// i.e. 4.1 TB/s in 283 us: the launch was bound by its own over-fetch (profiles/r02_hbm_counters_per_kernel.txt).
-template <typename T> struct ChTile { static constexpr int TT = 64 / (int)sizeof(T); };
+// Tokens per tile: a tile row is ONE 128-byte line for every I/O type (32 fp32 / 64 16-bit tokens).  With 32-byte pieces (16
+// tokens of bf16, the first version) a line of a row was fetched for four separate tiles, microseconds apart, with 2048
+// waves x 64 rows x 3 streams of such lines in flight -- far more than the L2s hold: rocprofv3 counted 1.17 GB of HBM
+// traffic per launch against 0.25 GB algorithmic at cfg 2's grouped stage 0 (4.1 TB/s in 283 us) and 4.6 GB against 1.76 GB
+// at cfg 3's stage 0 (4.8 TB/s in 962 us): the launches were bound by their own over-fetch
+// (profiles/r02_hbm_counters_per_kernel.txt).  Whole lines need 18 KB of LDS per wave for TWO resident streams, which is
+// what 8 waves per CU can have: z no longer goes through LDS -- the gate out * silu(z) is applied in the store phase, where
+// the lanes lie along tokens again and z is read with the same coalesced vectors the outputs are written with; y waits for it
+// in LDS as fp32, in the bytes of the u / delta tokens it was computed from.
+template <typename T> struct ChTile { static constexpr int TT = 128 / (int)sizeof(T); };
 
 int scan_ckpt_len(const vivim_ssm_fwd_params&);                          // scan_fwd.hip
 
@@ -190,7 +194,7 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
     constexpr int RPI = kWave / LPR;                  // rows per cooperative load/store instruction
     constexpr int NIO = kWave / RPI;                  // instructions per tile and stream
     constexpr int ROWB = RB + 16;                     // padded LDS row, bytes (conflict-free 8/16-byte own-row access)
-    constexpr int NARR = PASS == 2 && HAS_Z ? 3 : 2;  // resident tiles: u, delta (, z)
+    constexpr int NARR = 2;                           // resident tiles: u, delta
     constexpr int TB = 4;                             // tokens per compute block (L % TB == 0, sg.ck % TB == 0)
     typedef uint32_t __attribute__((ext_vector_type(4))) v4;
     typedef typename Pack<T, TB * (int)sizeof(T)>::type vblk;
@@ -211,7 +215,6 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
 
     unsigned char* tile_u = lds + (wave * NARR + 0) * kWave * ROWB;
     unsigned char* tile_d = lds + (wave * NARR + 1) * kWave * ROWB;
-    unsigned char* tile_z = lds + (wave * NARR + (NARR - 1)) * kWave * ROWB;   // only used when NARR == 3
 
     cf2 A2p[N / 2], hp[N / 2];                        // state pairs (2j, 2j + 1)
     {
@@ -248,7 +251,7 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
     // Tile I/O is double-buffered through registers: while tile i is processed out of LDS, the global loads of tile
     // i + 1 are in flight into `nu / nd / nz`; they are written to LDS after tile i's results have left it.
     union tile_regs { RawK<T, EPV> r; v4 v; };
-    tile_regs nu[NIO], nd[NIO], nz[NIO];
+    tile_regs nu[NIO], nd[NIO];
     auto issue_tile_loads = [&](int tile) {
         if (kChAbl == 2 && tile > tile_lo) return;
         kparams_t q = fresh_params();
@@ -264,12 +267,6 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
             nu[i].v = *reinterpret_cast<const v4*>(gu + i * RPI * su);
             nd[i].v = *reinterpret_cast<const v4*>(gd + i * RPI * sd);
         }
-        if (NARR == 3) {
-            const int64_t sz = q->z_d_stride;
-            const T* gz = static_cast<const T*>(q->z) + b * q->z_batch_stride + (c0 + io_row0) * sz + t;
-#pragma unroll
-            for (int i = 0; i < NIO; ++i) nz[i].v = *reinterpret_cast<const v4*>(gz + i * RPI * sz);
-        }
     };
     auto tile_regs_to_lds = [&] {
 #pragma unroll
@@ -277,7 +274,6 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
             const int off = (i * RPI + io_row0) * ROWB + io_col * 16;
             *reinterpret_cast<v4*>(tile_u + off) = nu[i].v;
             *reinterpret_cast<v4*>(tile_d + off) = nd[i].v;
-            if (NARR == 3) *reinterpret_cast<v4*>(tile_z + off) = nz[i].v;
         }
     };
     issue_tile_loads(tile_lo);
@@ -296,17 +292,13 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
         for (int blk = 0; blk < TT / TB; ++blk) {
             const int tb = __builtin_amdgcn_readfirstlane(t0 + blk * TB);
             if (tb >= L) break;                          // blocks never straddle L: nothing to mask below
-            float uf[TB], df[TB], zf[TB], yo[TB], dl[TB], w[TB];
+            float uf[TB], df[TB], yo[TB], dl[TB], w[TB];
             {
-                union { RawK<T, TB> r; vblk v; } cu, cd, cz;
+                union { RawK<T, TB> r; vblk v; } cu, cd;
                 cu.v = *reinterpret_cast<const vblk*>(tile_u + lane * ROWB + blk * TB * (int)sizeof(T));
                 cd.v = *reinterpret_cast<const vblk*>(tile_d + lane * ROWB + blk * TB * (int)sizeof(T));
                 unpack(cu.r, uf);
                 unpack(cd.r, df);
-                if (NARR == 3) {
-                    cz.v = *reinterpret_cast<const vblk*>(tile_z + lane * ROWB + blk * TB * (int)sizeof(T));
-                    unpack(cz.r, zf);
-                }
             }
 #pragma unroll
             for (int k = 0; k < TB; ++k) {
@@ -334,37 +326,57 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
 #pragma unroll
                     for (int n = 0; n < N; ++n) xr[n] = (n & 1) ? hp[n / 2].y : hp[n / 2].x;
                 }
-                // results overwrite the lane's own consumed input columns
-                union { T e[TB]; vblk v; } co, cz;
-#pragma unroll
-                for (int k = 0; k < TB; ++k) co.e[k] = from_f32<T>(yo[k]);
-                *reinterpret_cast<vblk*>(tile_u + lane * ROWB + blk * TB * (int)sizeof(T)) = co.v;
-                if (HAS_Z) {
-#pragma unroll
-                    for (int k = 0; k < TB; ++k)
-                        cz.e[k] = from_f32<T>(yo[k] * zf[k] * sigmoidf_fast(zf[k]));            // fwd_kernel.cuh:290
-                    *reinterpret_cast<vblk*>(tile_z + lane * ROWB + blk * TB * (int)sizeof(T)) = cz.v;
+                // y (fp32) replaces the inputs it was computed from: exactly as many bytes.  fp32 I/O: the block's four u
+                // values.  16-bit I/O: tokens 0, 1 of the block over its four u values, tokens 2, 3 over its four delta values.
+                static_assert(TB == 4, "the in-place y layout is written for blocks of four tokens");
+                if (sizeof(T) == 4) {
+                    *reinterpret_cast<float4*>(tile_u + lane * ROWB + blk * 16) = float4{yo[0], yo[1], yo[2], yo[3]};
+                } else {
+                    *reinterpret_cast<float2*>(tile_u + lane * ROWB + blk * 8) = float2{yo[0], yo[1]};
+                    *reinterpret_cast<float2*>(tile_d + lane * ROWB + blk * 8) = float2{yo[2], yo[3]};
                 }
             }
         }
         wave_lds_fence();
-        if (PASS == 2 && kChAbl != 3) {                // LDS -> global, coalesced
+        if (PASS == 2 && kChAbl != 3) {                // LDS -> global, coalesced; the gate is applied here
             kparams_t q = fresh_params();
             const int t = t0 + io_col * EPV;
             if (t < L) {
+                tile_regs gz[NIO];
+                if (HAS_Z) {                           // the tile's z, with the vectors the outputs are written with
+                    const int64_t sz = q->z_d_stride;
+                    const T* gzp = static_cast<const T*>(q->z) + b * q->z_batch_stride + (c0 + io_row0) * sz + t;
+#pragma unroll
+                    for (int i = 0; i < NIO; ++i) gz[i].v = *reinterpret_cast<const v4*>(gzp + i * RPI * sz);
+                }
                 const int64_t so = q->out_d_stride;
                 T* go = static_cast<T*>(q->out) + b * q->out_batch_stride + (c0 + io_row0) * so + t;
+                const int64_t soz = HAS_Z ? q->out_z_d_stride : 0;
+                T* goz = HAS_Z ? static_cast<T*>(q->out_z) + b * q->out_z_batch_stride + (c0 + io_row0) * soz + t : nullptr;
 #pragma unroll
-                for (int i = 0; i < NIO; ++i)
-                    *reinterpret_cast<v4*>(go + i * RPI * so) =
-                        *reinterpret_cast<const v4*>(tile_u + (i * RPI + io_row0) * ROWB + io_col * 16);
-                if (HAS_Z) {
-                    const int64_t soz = q->out_z_d_stride;
-                    T* goz = static_cast<T*>(q->out_z) + b * q->out_z_batch_stride + (c0 + io_row0) * soz + t;
+                for (int i = 0; i < NIO; ++i) {
+                    const int off = (i * RPI + io_row0) * ROWB + io_col * 16;
+                    float y[EPV];
+                    if (sizeof(T) == 4) {
+                        const float4 a = *reinterpret_cast<const float4*>(tile_u + off);
+                        y[0] = a.x; y[1] = a.y; y[2] = a.z; y[3] = a.w;
+                    } else {                           // tokens 8c .. 8c+7: (0, 1, 4, 5) from the u row, (2, 3, 6, 7) from the delta row
+                        const float4 a = *reinterpret_cast<const float4*>(tile_u + off);
+                        const float4 d4 = *reinterpret_cast<const float4*>(tile_d + off);
+                        y[0] = a.x; y[1] = a.y; y[2] = d4.x; y[3] = d4.y;
+                        y[4 % EPV] = a.z; y[5 % EPV] = a.w; y[6 % EPV] = d4.z; y[7 % EPV] = d4.w;
+                    }
+                    union { T e[EPV]; v4 v; } co;
 #pragma unroll
-                    for (int i = 0; i < NIO; ++i)
-                        *reinterpret_cast<v4*>(goz + i * RPI * soz) =
-                            *reinterpret_cast<const v4*>(tile_z + (i * RPI + io_row0) * ROWB + io_col * 16);
+                    for (int k = 0; k < EPV; ++k) co.e[k] = from_f32<T>(y[k]);
+                    *reinterpret_cast<v4*>(go + i * RPI * so) = co.v;
+                    if (HAS_Z) {
+                        float zf[EPV];
+                        unpack(gz[i].r, zf);
+#pragma unroll
+                        for (int k = 0; k < EPV; ++k) co.e[k] = from_f32<T>(y[k] * zf[k] * sigmoidf_fast(zf[k]));   // fwd_kernel.cuh:290
+                        *reinterpret_cast<v4*>(goz + i * RPI * soz) = co.v;
+                    }
                 }
             }
             wave_lds_fence();
