@@ -203,11 +203,23 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.y, seg = blockIdx.z;
+    // Workgroups are dealt round-robin over the 8 XCDs (blocks i and i + 8 share one; MI355X_MICROARCH.md, workgroup
+    // dispatch).  The workgroups of one (batch, group, segment) read the same B / C rows: numbered consecutively they
+    // would pull those rows into three or more L2s (a third of this kernel's reads at cfg 2's stage 0); re-numbered so
+    // that consecutive work items are 8 blocks apart they meet in one.  Speed only: nothing depends on the placement.
+    int bx = blockIdx.x, b = blockIdx.y, seg = blockIdx.z;
+    {
+        const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+        if (total % 8 == 0) {
+            const unsigned flat = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+            const unsigned w = (flat % 8) * (total / 8) + flat / 8;
+            bx = (int)(w % gx); b = (int)((w / gx) % gy); seg = (int)(w / (gx * gy));
+        }
+    }
     const int L = p.seqlen;
     const int cpg = p.dim / p.n_groups;               // % 64 == 0 (host)
     const int bpg = cpg / kWave;                      // 64-channel blocks per B/C group
-    const int cb = blockIdx.x * kChWaves + wave;
+    const int cb = bx * kChWaves + wave;
     if (cb >= bpg * p.n_groups) return;               // waves are independent: no barrier below
     const int g = cb / bpg;
     const int c0 = cb * kWave;
@@ -244,7 +256,7 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
     float l2_touch = 0.0f;
     // one BC row is [B0-7 | C0-7 | B8-15 | C8-15]: a half token = 16 consecutive floats (t <= Lpad: Lpad + 1 rows)
     // the segment's first tile is touched here (vector load, L2 allocate) so that its scalar loads do not go to HBM
-    if (lane < TT * 2) l2_touch = bc[(int64_t)min(tile_lo * TT + (lane >> 1), sg.Lpad) * 32 + (lane & 1) * 16];
+    if (lane < TT) l2_touch = bc[(int64_t)min(tile_lo * TT + lane, sg.Lpad) * 32];      // one lane per 128-byte BC row
     asm volatile("s_waitcnt vmcnt(0)" : : "v"(l2_touch));
     chan_prime_x<PASS>(bc + (int64_t)tile_lo * TT * 32);
 
@@ -258,7 +270,9 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
         // Unconditional loads (countable vmcnt: a load under a branch would make the next wait a full drain); columns past
         // the end are clamped onto the row's last vector -- their tokens are never processed (blocks stop at L, the
         // tile after the segment's last is never read)
-        const int t = min(__builtin_amdgcn_readfirstlane(tile * TT) + io_col * EPV, L - EPV);
+        // (the request after the segment's last tile re-reads that tile -- an L2 hit -- instead of fetching a tile of the
+        // next segment that nobody uses: with three or four tiles per segment that was a quarter of the launch's reads)
+        const int t = min(__builtin_amdgcn_readfirstlane(min(tile, tile_hi - 1) * TT) + io_col * EPV, L - EPV);
         const int64_t su = q->u_d_stride, sd = q->delta_d_stride;
         const T* gu = static_cast<const T*>(q->u) + b * q->u_batch_stride + (c0 + io_row0) * su + t;
         const T* gd = static_cast<const T*>(q->delta) + b * q->delta_batch_stride + (c0 + io_row0) * sd + t;
@@ -285,7 +299,7 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
         const int t0 = __builtin_amdgcn_readfirstlane(tile * TT);
         // one vector load touches the 64-byte lines of the NEXT tile's BC rows: they are in this XCD's L2 by the time
         // the scalar loads want them (first touch would otherwise come from beyond the L2)
-        if (lane < TT * 2) l2_touch = bc[(int64_t)min(t0 + TT + (lane >> 1), sg.Lpad) * 32 + (lane & 1) * 16];
+        if (lane < TT) l2_touch = bc[(int64_t)min(t0 + TT + lane, sg.Lpad) * 32];
         issue_tile_loads(tile + 1);                       // predicated off past the segment's last tile
         // ---- the lane's own row: TT tokens in blocks of TB (one 8- or 16-byte LDS access per stream) ----
 #pragma unroll 1
