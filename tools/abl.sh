@@ -13,6 +13,20 @@ if [ "$mode" = chanbuild ]; then     # lanes=channels forward ablations (-DCH_AB
   done
   exit 0
 fi
+if [ "$mode" = bwdbuild ]; then      # round-1 backward without its dB / dC atomics (-DBW_ABL=1)
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -DBW_ABL=1 -c scan_bwd.hip -o abl/scan_bwd_1.o 2> abl/scan_bwd_1.res
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o abl/libvivim_bwabl_1.so capi.o conv1d.o conv1d_cl.o scan_fwd.o scan_fwd_chan.o scan_ls.o abl/scan_bwd_1.o dwconv.o dirmap.o update.o
+  echo "built bwd abl 1"; exit 0
+fi
+if [ "$mode" = bwdrun ]; then
+  cd ../..
+  for lib in libvivim_hip.so abl/libvivim_bwabl_1.so; do
+    echo "== $lib"
+    VIVIM_LIB=$PWD/vivim_amd/csrc/$lib python tools/kbench.py --config 3 --stages 0 --kernels sb --iters 6 | grep stage
+    VIVIM_LIB=$PWD/vivim_amd/csrc/$lib python tools/kbench.py --config 2 --groups 3 --stages 0 --kernels sb --iters 20 | grep stage
+  done
+  exit 0
+fi
 if [ "$mode" = chanrun ]; then
   cd ../..
   for n in "$@"; do

@@ -551,7 +551,11 @@ __global__ void __launch_bounds__(W * kWave, (K == 4 && W == 4) ? 3 : 2) ssm_bwd
                     // carry acc == 0 (their dy and delta*u are 0) and are wrapped onto distinct valid tokens.
                     const int tq = step * TILE + e_tok;
                     const int t = tq < L ? tq : tq % L;
+#if defined(BW_ABL) && BW_ABL == 1               // timing experiment (tools/abl.sh bwdbuild): no dB / dC atomics -- wrong results
+                    asm volatile("" : : "v"(acc), "v"(t));
+#else
                     atomicAdd((e_isC ? dCg + n * p.dC_dstate_stride : dBg + n * p.dB_dstate_stride) + t, acc);
+#endif
                 }
                 if (n == 1) VIVIM_STAMP(nsteps - 1 - step, 9, wave, lane);
             }

@@ -290,6 +290,18 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
             *reinterpret_cast<v4*>(tile_d + off) = nd[i].v;
         }
     };
+    // z of the tile being computed: requested at the tile's start with the vectors of the store phase, consumed there.
+    // (Registers are free for it: two resident tile streams already cap the kernel at two waves per SIMD.)
+    tile_regs gz[NIO];
+    auto issue_z_loads = [&](int tile) {
+        if (!(PASS == 2 && HAS_Z) || kChAbl == 2) return;
+        kparams_t q = fresh_params();
+        const int t = min(__builtin_amdgcn_readfirstlane(tile * TT) + io_col * EPV, L - EPV);
+        const int64_t sz = q->z_d_stride;
+        const T* gzp = static_cast<const T*>(q->z) + b * q->z_batch_stride + (c0 + io_row0) * sz + t;
+#pragma unroll
+        for (int i = 0; i < NIO; ++i) gz[i].v = *reinterpret_cast<const v4*>(gzp + i * RPI * sz);
+    };
     issue_tile_loads(tile_lo);
     tile_regs_to_lds();
     wave_lds_fence();
@@ -300,7 +312,8 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
         // one vector load touches the 64-byte lines of the NEXT tile's BC rows: they are in this XCD's L2 by the time
         // the scalar loads want them (first touch would otherwise come from beyond the L2)
         if (lane < TT) l2_touch = bc[(int64_t)min(t0 + TT + lane, sg.Lpad) * 32];
-        issue_tile_loads(tile + 1);                       // predicated off past the segment's last tile
+        issue_tile_loads(tile + 1);                       // (past the segment's last tile: that tile again)
+        issue_z_loads(tile);
         // ---- the lane's own row: TT tokens in blocks of TB (one 8- or 16-byte LDS access per stream) ----
 #pragma unroll 1
         for (int blk = 0; blk < TT / TB; ++blk) {
@@ -356,13 +369,6 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
             kparams_t q = fresh_params();
             const int t = t0 + io_col * EPV;
             if (t < L) {
-                tile_regs gz[NIO];
-                if (HAS_Z) {                           // the tile's z, with the vectors the outputs are written with
-                    const int64_t sz = q->z_d_stride;
-                    const T* gzp = static_cast<const T*>(q->z) + b * q->z_batch_stride + (c0 + io_row0) * sz + t;
-#pragma unroll
-                    for (int i = 0; i < NIO; ++i) gz[i].v = *reinterpret_cast<const v4*>(gzp + i * RPI * sz);
-                }
                 const int64_t so = q->out_d_stride;
                 T* go = static_cast<T*>(q->out) + b * q->out_batch_stride + (c0 + io_row0) * so + t;
                 const int64_t soz = HAS_Z ? q->out_z_d_stride : 0;
