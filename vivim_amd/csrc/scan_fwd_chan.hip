@@ -53,6 +53,7 @@ struct FwdSeg {
     const float* BC;               // [batch][groups][Lpad + 1][32]  fp32 token-major B / C (ssm_fwd_bc_kernel)
     int Lpad;
     int ck;                        // tokens per checkpoint row of x (scan_ckpt_len: 16 for the lanes = states backward, else kChunk)
+    int xcd;                       // re-number the workgroups so that those sharing B / C rows share an XCD (see the kernel)
 };
 
 
@@ -210,7 +211,7 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
     int bx = blockIdx.x, b = blockIdx.y, seg = blockIdx.z;
     {
         const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
-        if (total % 8 == 0) {
+        if (sg.xcd && total % 8 == 0) {
             const unsigned flat = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
             const unsigned w = (flat % 8) * (total / 8) + flat / 8;
             bx = (int)(w % gx); b = (int)((w / gx) % gy); seg = (int)(w / (gx * gy));
@@ -534,7 +535,13 @@ static bool launch_fwd_chan(const vivim_ssm_fwd_params& p, hipStream_t stream) {
     size_t bc_floats;
     const size_t need = fwd_chan_layout(p, TT, S, seg_tiles, Lpad, bc_floats);
     if (!p.workspace || (size_t)p.workspace_bytes < need || (reinterpret_cast<uintptr_t>(p.workspace) & 63)) return false;
-    FwdSeg sg = {S, seg_tiles, nullptr, nullptr, static_cast<const float*>(p.workspace), Lpad, scan_ckpt_len(p)};
+    // Measured, VIVIM_CHAN_XCD=0 / 1 (profiles/r02_chan_xcd_ab.log): the re-numbering gains 2 - 5 % on the bf16 grouped shapes
+    // and where two workgroups share a group's B / C rows (cfg 3 stage 1), and loses 2 - 10 % on fp32 problems with one
+    // workgroup per group (cfg 3 stage 0: 831 -> 845 us; grouped 2563 -> 2807 us).
+    static const int xcd_env = getenv("VIVIM_CHAN_XCD") ? atoi(getenv("VIVIM_CHAN_XCD")) : -1;
+    const int wg_per_group = ((p.dim / p.n_groups) / kWave + kChWaves - 1) / kChWaves;
+    const int xcd = xcd_env >= 0 ? xcd_env : ((wg_per_group >= 2 || p.itype != VIVIM_F32) ? 1 : 0);
+    FwdSeg sg = {S, seg_tiles, nullptr, nullptr, static_cast<const float*>(p.workspace), Lpad, scan_ckpt_len(p), xcd};
     if (S > 1) {
         sg.H = static_cast<float*>(p.workspace) + bc_floats;
         sg.dsum = sg.H + (size_t)p.batch * p.dim * S * kChN;
