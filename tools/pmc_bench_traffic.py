@@ -53,7 +53,7 @@ if __name__ == "__main__":
                   "hbm_bytes_per_launch": int((2 * fetch[g] / nf[g] + write[g] / nw[g]) * 1024)}
         if nv.get(g):
             res[g]["valu_wave_insts_per_launch"] = int(valu[g] / nv[g])
-    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU passes (one counter per pass) over `bench.py --steps 3 "
+    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU passes (one counter per pass) over `bench.py --steps 2 "
                        "--warmup 1`; reads doubled (gfx950); launches counted from the profile",
                "kernels_sha": kernels_sha(), "per_entry_point": res}, open(sys.argv[4], "w"), indent=1)
     print(json.dumps(res, indent=1))

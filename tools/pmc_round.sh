@@ -8,7 +8,7 @@ out=$root/gpurun_out
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$out/pmc_$c" -o b -- python3 "$root/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-by-config > "$out/pmc_$c.log" 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$out/pmc_$c" -o b -- python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-by-config > "$out/pmc_$c.log" 2>&1
   echo "pass $c done"
 done
 cd "$root"
