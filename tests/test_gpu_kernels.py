@@ -405,6 +405,19 @@ def test_scan_kernel_families(fwd, bwd, dtype, batch, dim, L, G, cuda, ops, tuni
     _check_scan(_rand_scan(gen, batch, dim, 16, L, G, dtype, cuda, init="module"), ss)
 
 
+@pytest.mark.parametrize("fwd", ["auto", "nsplit_k8", "generic", "channels", "states"])
+@pytest.mark.parametrize("bwd", ["auto", "fast_w4", "generic", "states"])
+@pytest.mark.parametrize("dtype,batch,dim,L,G", [(torch.bfloat16, 1, 384, 4104, 3), (torch.float32, 2, 64, 1000, 1),
+                                                (torch.float16, 2, 128, 72, 2)])
+def test_scan_kernel_families_dstate64(fwd, bwd, dtype, batch, dim, L, G, cuda, ops, tuning):
+    """BASELINE.json configs[4]'s state size through every family that takes it: lanes=channels walks a token's 64 states as
+    four 16-state chunks over the two scalar B / C sets (round 2), lanes=states gives a channel all four rows of a wave."""
+    ss, _ = ops
+    tuning(FWD_VARIANTS[fwd], BWD_VARIANTS[bwd])
+    gen = torch.Generator().manual_seed(dim + L)
+    _check_scan(_rand_scan(gen, batch, dim, 64, L, G, dtype, cuda, init="module"), ss)
+
+
 @pytest.mark.parametrize("fwd", ["nsplit_k8", "channels", "states"])
 def test_scan_kernel_families_strided_long(fwd, cuda, ops, tuning):
     """(L, B*L, 1)-strided rows, many token-axis segments (L = 20480: S > 1 in the channels kernels)."""

@@ -57,14 +57,16 @@ struct FwdSeg {
 };
 
 
-// BC[b][g][t] = [B_0..7 | C_0..7 | B_8..15 | C_8..15](t) as fp32; zero rows for L <= t <= Lpad (Lpad + 1 rows).
+// BC[b][g][t][chunk] = [B_0..7 | C_0..7 | B_8..15 | C_8..15] of the chunk's 16 states (chunk = state / 16; one chunk at
+// dstate 16, four at dstate 64) as fp32; zero rows for L <= t <= Lpad (Lpad + 1 rows).  grid.y = groups * chunks.
 template <typename T>
 __global__ void __launch_bounds__(256) ssm_fwd_bc_kernel(const vivim_ssm_fwd_params p, float* __restrict__ BC, int Lpad) {
     __shared__ float tile[64][33];
     const int tid = threadIdx.x;
-    const int t0 = blockIdx.x * 64, g = blockIdx.y, b = blockIdx.z;
-    const T* __restrict__ Bp = static_cast<const T*>(p.B) + b * p.B_batch_stride + g * p.B_group_stride;
-    const T* __restrict__ Cp = static_cast<const T*>(p.C) + b * p.C_batch_stride + g * p.C_group_stride;
+    const int nch = p.dstate / 16;
+    const int t0 = blockIdx.x * 64, g = blockIdx.y / nch, kch = blockIdx.y - g * nch, b = blockIdx.z;
+    const T* __restrict__ Bp = static_cast<const T*>(p.B) + b * p.B_batch_stride + g * p.B_group_stride + kch * 16 * p.B_dstate_stride;
+    const T* __restrict__ Cp = static_cast<const T*>(p.C) + b * p.C_batch_stride + g * p.C_group_stride + kch * 16 * p.C_dstate_stride;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int row = i * 4 + (tid >> 6), t = t0 + (tid & 63);
@@ -74,11 +76,11 @@ __global__ void __launch_bounds__(256) ssm_fwd_bc_kernel(const vivim_ssm_fwd_par
         tile[tid & 63][((row & 8) << 1) | ((row >> 4) << 3) | (row & 7)] = v;   // [B0-7 | C0-7 | B8-15 | C8-15]
     }
     __syncthreads();
-    float* __restrict__ dst = BC + ((int64_t)(b * p.n_groups + g) * (Lpad + 1) + t0) * 32;   // + 1: prefetch overrun row
+    float* __restrict__ dst = BC + (((int64_t)(b * p.n_groups + g) * (Lpad + 1) + t0) * nch + kch) * 32;   // + 1: prefetch overrun row
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int idx = i * 256 + tid;
-        if (t0 + (idx >> 5) <= Lpad) dst[idx] = tile[idx >> 5][idx & 31];
+        if (t0 + (idx >> 5) <= Lpad) dst[(int64_t)(idx >> 5) * 32 * nch + (idx & 31)] = tile[idx >> 5][idx & 31];
     }
 }
 
@@ -184,10 +186,11 @@ __device__ __forceinline__ kparams_t fresh_params() {
     return q;
 }
 
-template <typename T, int PASS, bool HAS_Z>
+template <typename T, int PASS, bool HAS_Z, int NST = kChN>
 __global__ void __launch_bounds__(kChWaves * kWave) __attribute__((amdgpu_num_sgpr(kChSgprLimit)))
 ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
-    constexpr int N = kChN;
+    constexpr int N = NST;                            // 16, or 64 as four chunks of 16 per token (the scalar sets hold one chunk)
+    constexpr int NCH = N / 16;
     constexpr int EPV = 16 / (int)sizeof(T);          // elements per 16-byte vector
     constexpr int TT = ChTile<T>::TT;                 // tokens per tile
     constexpr int RB = TT * (int)sizeof(T);           // bytes of a row inside a tile (32 for 16-bit, 64 for fp32)
@@ -242,7 +245,7 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
     const float Dv = p.D ? static_cast<const float*>(p.D)[d] : 0.0f;
     const float bias = p.delta_bias ? static_cast<const float*>(p.delta_bias)[d] : 0.0f;
     const bool sp_on = p.delta_softplus;
-    const float* __restrict__ bc = sg.BC + (int64_t)(b * p.n_groups + g) * (sg.Lpad + 1) * 32;
+    const float* __restrict__ bc = sg.BC + (int64_t)(b * p.n_groups + g) * (sg.Lpad + 1) * 32 * NCH;
     const int ck = sg.ck;
     const int nck = (L + ck - 1) / ck;
     float* __restrict__ xlane = static_cast<float*>(p.x) + ((int64_t)b * p.dim + d) * nck * N;   // per-lane (VGPRs)
@@ -257,9 +260,9 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
     float l2_touch = 0.0f;
     // one BC row is [B0-7 | C0-7 | B8-15 | C8-15]: a half token = 16 consecutive floats (t <= Lpad: Lpad + 1 rows)
     // the segment's first tile is touched here (vector load, L2 allocate) so that its scalar loads do not go to HBM
-    if (lane < TT) l2_touch = bc[(int64_t)min(tile_lo * TT + lane, sg.Lpad) * 32];      // one lane per 128-byte BC row
+    if (lane < TT) l2_touch = bc[(int64_t)min(tile_lo * TT + lane, sg.Lpad) * 32 * NCH];   // one lane per BC row (its first line)
     asm volatile("s_waitcnt vmcnt(0)" : : "v"(l2_touch));
-    chan_prime_x<PASS>(bc + (int64_t)tile_lo * TT * 32);
+    chan_prime_x<PASS>(bc + (int64_t)tile_lo * TT * 32 * NCH);
 
     // Tile I/O is double-buffered through registers: while tile i is processed out of LDS, the global loads of tile
     // i + 1 are in flight into `nu / nd / nz`; they are written to LDS after tile i's results have left it.
@@ -312,9 +315,9 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
         const int t0 = __builtin_amdgcn_readfirstlane(tile * TT);
         // one vector load touches the 64-byte lines of the NEXT tile's BC rows: they are in this XCD's L2 by the time
         // the scalar loads want them (first touch would otherwise come from beyond the L2)
-        if (lane < TT) l2_touch = bc[(int64_t)min(t0 + TT + lane, sg.Lpad) * 32];
+        if (lane < TT) l2_touch = bc[(int64_t)min(t0 + TT + lane, sg.Lpad) * 32 * NCH];
         issue_tile_loads(tile + 1);                       // (past the segment's last tile: that tile again)
-        issue_z_loads(tile);
+        if (NCH == 1) issue_z_loads(tile);                // (64 states: no registers left -- requested in the store phase)
         // ---- the lane's own row: TT tokens in blocks of TB (one 8- or 16-byte LDS access per stream) ----
 #pragma unroll 1
         for (int blk = 0; blk < TT / TB; ++blk) {
@@ -336,15 +339,29 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
                 dsum += dl[k];
                 yo[k] = Dv * uf[k];
             }
-            const float* bct = bc + (int64_t)tb * 32;     // uniform: this block's first BC row
+            const float* bct = bc + (int64_t)tb * 32 * NCH;   // uniform: this block's first BC row
+            if constexpr (NCH == 1) {
 #pragma unroll
-            for (int k = 0; k < TB; k += 2) {             // tokens alternate between the two scalar sets
-                cf2 y2 = {yo[k], 0.0f};
-                chan_token_x<PASS>(hp, A2p, dl[k], w[k], y2, bct + (k + 1) * 32);             // prefetch: token k + 1 -> Y
-                if (PASS == 2) yo[k] = y2.x + y2.y;
-                y2 = cf2{yo[k + 1], 0.0f};
-                chan_token_y<PASS>(hp, A2p, dl[k + 1], w[k + 1], y2, bct + (k + 2) * 32);     // token k + 2 -> X
-                if (PASS == 2) yo[k + 1] = y2.x + y2.y;
+                for (int k = 0; k < TB; k += 2) {         // tokens alternate between the two scalar sets
+                    cf2 y2 = {yo[k], 0.0f};
+                    chan_token_x<PASS>(hp, A2p, dl[k], w[k], y2, bct + (k + 1) * 32);             // prefetch: token k + 1 -> Y
+                    if (PASS == 2) yo[k] = y2.x + y2.y;
+                    y2 = cf2{yo[k + 1], 0.0f};
+                    chan_token_y<PASS>(hp, A2p, dl[k + 1], w[k + 1], y2, bct + (k + 2) * 32);     // token k + 2 -> X
+                    if (PASS == 2) yo[k + 1] = y2.x + y2.y;
+                }
+            } else {
+                static_assert(NCH == 1 || NCH == 4, "the chunk sequence X, Y, X, Y is written for four chunks");
+#pragma unroll
+                for (int k = 0; k < TB; ++k) {            // a token's four 16-state chunks alternate between the sets
+                    const float* row = bct + k * 32 * NCH;
+                    cf2 y2 = {yo[k], 0.0f};
+                    chan_token_x<PASS>(hp, A2p, dl[k], w[k], y2, row + 32);                  // chunk 1 -> Y
+                    chan_token_y<PASS>(hp + 8, A2p + 8, dl[k], w[k], y2, row + 64);          // chunk 2 -> X
+                    chan_token_x<PASS>(hp + 16, A2p + 16, dl[k], w[k], y2, row + 96);        // chunk 3 -> Y
+                    chan_token_y<PASS>(hp + 24, A2p + 24, dl[k], w[k], y2, row + 32 * NCH);  // the next token's chunk 0 -> X
+                    if (PASS == 2) yo[k] = y2.x + y2.y;
+                }
             }
             if (PASS == 2) {
                 // state after every ck tokens and after the last one: always the last token of a block
@@ -370,6 +387,7 @@ ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
             kparams_t q = fresh_params();
             const int t = t0 + io_col * EPV;
             if (t < L) {
+                if (NCH != 1) issue_z_loads(tile);
                 const int64_t so = q->out_d_stride;
                 T* go = static_cast<T*>(q->out) + b * q->out_batch_stride + (c0 + io_row0) * so + t;
                 const int64_t soz = HAS_Z ? q->out_z_d_stride : 0;
@@ -462,6 +480,35 @@ __global__ void __launch_bounds__(kWave) ssm_fwd_carry_kernel(const vivim_ssm_fw
     }
 }
 
+// The same chain for 64 states: lane = state, segments in order, eight segments' operands requested together.
+__global__ void __launch_bounds__(kWave) ssm_fwd_carry64_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
+    constexpr int N = 64;
+    const int n = threadIdx.x;
+    const int64_t bd = blockIdx.x;
+    const int S = sg.S;
+    float* __restrict__ Hrow = sg.H + bd * S * N;
+    const float* __restrict__ drow = sg.dsum + bd * S;
+    const int dch = (int)(bd % p.dim);
+    const float A2 = static_cast<const float*>(p.A)[dch * p.A_d_stride + n * p.A_dstate_stride] * kLog2e;
+    float carry = 0.0f;
+    for (int s0 = 0; s0 < S; s0 += 8) {
+        float H[8], ds[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const bool ok = s0 + q < S;
+            H[q] = ok ? Hrow[(s0 + q) * N + n] : 0.0f;
+            ds[q] = ok ? drow[s0 + q] : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (s0 + q < S) {
+                Hrow[(s0 + q) * N + n] = carry;                       // the state flowing INTO segment s0 + q
+                carry = fmaf(fast_exp2(A2 * ds[q]), carry, H[q]);
+            }
+        }
+    }
+}
+
 static void fwd_chan_segmentation(const vivim_ssm_fwd_params& f, int tt, int& S, int& seg_tiles) {
     const int ntiles = (f.seqlen + tt - 1) / tt;
     const int cpg = f.dim / f.n_groups;
@@ -480,7 +527,7 @@ static void fwd_chan_segmentation(const vivim_ssm_fwd_params& f, int tt, int& S,
 
 // shape_only: pointers are not inspected (the workspace query may come before they are final)
 static bool fwd_chan_eligible(const vivim_ssm_fwd_params& p, bool shape_only = false) {
-    if (!p.is_variable_B || !p.is_variable_C || p.dstate != kChN || p.seqlen % 8 != 0) return false;
+    if (!p.is_variable_B || !p.is_variable_C || (p.dstate != 16 && p.dstate != 64) || p.seqlen % 8 != 0) return false;
     if (p.dim % p.n_groups != 0 || (p.dim / p.n_groups) % kWave != 0) return false;   // whole 64-channel blocks per group
     // Automatic choice, from tools/kbench.py on MI355X (us, this family vs n-split; cols = batch * dim / 64 waves' worth of
     // channels, work = cols * seqlen wave-tokens):
@@ -492,6 +539,7 @@ static bool fwd_chan_eligible(const vivim_ssm_fwd_params& p, bool shape_only = f
     const int tune = tuning_fwd_variant();
     if (tune != 5) {
         if (tune != 0) return false;
+        if (p.dstate == 64 && p.itype == VIVIM_F32) return false;   // 255 + 4 registers: one wave per SIMD (n-split is faster)
         const int64_t cols = (int64_t)p.batch * (p.dim / kWave);
         // short checkpoint rows (scan_ckpt_len): the alternative is the lanes = states forward, which wins below ~150 k
         // wave-tokens (cfg 2 grouped stages 1-3, 184 k / 115 k / 46 k: 150 / 98 / 51 us against 137 / 100 / 59 with 64-byte
@@ -516,8 +564,8 @@ static size_t fwd_chan_layout(const vivim_ssm_fwd_params& f, int tt, int& S, int
                               size_t& bc_floats) {
     fwd_chan_segmentation(f, tt, S, seg_tiles);
     Lpad = (f.seqlen + tt - 1) / tt * tt;
-    bc_floats = (size_t)f.batch * f.n_groups * (Lpad + 1) * 32;
-    const size_t h_floats = S > 1 ? (size_t)f.batch * f.dim * S * (kChN + 1) : 0;
+    bc_floats = (size_t)f.batch * f.n_groups * (Lpad + 1) * 32 * (f.dstate / 16);
+    const size_t h_floats = S > 1 ? (size_t)f.batch * f.dim * S * (f.dstate + 1) : 0;
     return (bc_floats + h_floats) * sizeof(float);
 }
 
@@ -544,20 +592,29 @@ static bool launch_fwd_chan(const vivim_ssm_fwd_params& p, hipStream_t stream) {
     FwdSeg sg = {S, seg_tiles, nullptr, nullptr, static_cast<const float*>(p.workspace), Lpad, scan_ckpt_len(p), xcd};
     if (S > 1) {
         sg.H = static_cast<float*>(p.workspace) + bc_floats;
-        sg.dsum = sg.H + (size_t)p.batch * p.dim * S * kChN;
+        sg.dsum = sg.H + (size_t)p.batch * p.dim * S * p.dstate;
     }
-    hipLaunchKernelGGL((ssm_fwd_bc_kernel<T>), dim3((Lpad + 1 + 63) / 64, p.n_groups, p.batch), dim3(256), 0, stream, p,
+    hipLaunchKernelGGL((ssm_fwd_bc_kernel<T>), dim3((Lpad + 1 + 63) / 64, p.n_groups * (p.dstate / 16), p.batch), dim3(256), 0, stream, p,
                        static_cast<float*>(p.workspace), Lpad);
     const int cpg = p.dim / p.n_groups;
     const int blocks = ((cpg / kWave) * p.n_groups + kChWaves - 1) / kChWaves;
-    const dim3 block(kChWaves * kWave);
+    const dim3 block(kChWaves * kWave), grid(blocks, p.batch, sg.S);
+    if (p.dstate == 64) {
+        if (sg.S > 1) {
+            hipLaunchKernelGGL((ssm_fwd_chan_kernel<T, 1, false, 64>), grid, block, 0, stream, p, sg);
+            hipLaunchKernelGGL(ssm_fwd_carry64_kernel, dim3((unsigned)(p.batch * p.dim)), dim3(kWave), 0, stream, p, sg);
+        }
+        if (p.z) hipLaunchKernelGGL((ssm_fwd_chan_kernel<T, 2, true, 64>), grid, block, 0, stream, p, sg);
+        else     hipLaunchKernelGGL((ssm_fwd_chan_kernel<T, 2, false, 64>), grid, block, 0, stream, p, sg);
+        return true;
+    }
     if (sg.S > 1) {
-        hipLaunchKernelGGL((ssm_fwd_chan_kernel<T, 1, false>), dim3(blocks, p.batch, sg.S), block, 0, stream, p, sg);
+        hipLaunchKernelGGL((ssm_fwd_chan_kernel<T, 1, false>), grid, block, 0, stream, p, sg);
         const size_t carry_lds = (size_t)sg.S * (kChN + 1) * sizeof(float);      // <= 34 KB (S <= 512)
         hipLaunchKernelGGL(ssm_fwd_carry_kernel, dim3((unsigned)(p.batch * p.dim)), dim3(kWave), carry_lds, stream, p, sg);
     }
-    if (p.z) hipLaunchKernelGGL((ssm_fwd_chan_kernel<T, 2, true>), dim3(blocks, p.batch, sg.S), block, 0, stream, p, sg);
-    else     hipLaunchKernelGGL((ssm_fwd_chan_kernel<T, 2, false>), dim3(blocks, p.batch, sg.S), block, 0, stream, p, sg);
+    if (p.z) hipLaunchKernelGGL((ssm_fwd_chan_kernel<T, 2, true>), grid, block, 0, stream, p, sg);
+    else     hipLaunchKernelGGL((ssm_fwd_chan_kernel<T, 2, false>), grid, block, 0, stream, p, sg);
     return true;
 }
 
