@@ -42,7 +42,11 @@ def total(d, counter):
 
 
 if __name__ == "__main__":
-    (fetch, nf), (write, nw) = total(sys.argv[1], "FETCH_SIZE"), total(sys.argv[2], "WRITE_SIZE")
+    (fetch, nf) = total(sys.argv[1], "FETCH_SIZE")
+    (write, nw) = total(sys.argv[2], "WRITE_SIZE")
+    if not nw:                                       # raw request counters instead of the derived metric (KiB like WRITE_SIZE)
+        (wr, nw), (wr64, _) = total(sys.argv[2], "TCC_EA0_WRREQ_sum"), total(sys.argv[2], "TCC_EA0_WRREQ_64B_sum")
+        write = {g: ((wr[g] - wr64.get(g, 0.0)) * 32 + wr64.get(g, 0.0) * 64) / 1024 for g in wr}
     valu, nv = total(sys.argv[3], "SQ_INSTS_VALU") if sys.argv[3] != "-" else ({}, {})
     res = {}
     for g in GROUPS:
