@@ -19,7 +19,10 @@
  *     (seqlen) axis of every activation tensor has unit stride; batch / channel strides are free
  *     (Vivim passes halves of `xz`, strides (L, B*L, 1) -- mamba_simple.py:204-208).
  *   - the call only enqueues kernels on `stream` (a hipStream_t, NULL = default stream): it never
- *     synchronises, allocates or frees, and keeps no state between calls (re-entrant).
+ *     synchronises, allocates or frees, and keeps no per-call state (re-entrant).  The one piece of process-global
+ *     mutable state is the kernel-selection override of vivim_set_tuning() (tests / tuning only, default 0 = automatic):
+ *     it also changes vivim_scan_ckpt_len(), so it must not be changed between a forward call and its backward call or
+ *     while another thread is inside the library.
  *   - outputs are caller-allocated.  Accumulated outputs (dA, dB, dC, dD, ddelta_bias, dweight,
  *     dbias) are float32 and MUST be zero-filled by the caller before the call, exactly as the
  *     reference binding does (selective_scan.cpp:458-466, causal_conv1d.cpp:247-249).

@@ -506,6 +506,10 @@ FULL = [c + (1,) for c in FULL] + [  # the grouped v3 shapes: three directions s
     ("cfg2_stage0_grouped", 3, 384, 16, 20480, torch.bfloat16, 3),
     ("cfg2_stage3_grouped", 3, 3072, 16, 320, torch.bfloat16, 3),
     ("cfg3_stage1_grouped", 8, 768, 16, 20480, torch.float32, 3),
+    # the exact launches bench.py times for configs[2] and configs[4]
+    ("cfg3_stage0_grouped", 8, 384, 16, 81920, torch.float32, 3),
+    ("cfg5_stage0_grouped", 1, 768, 64, 32768, torch.bfloat16, 3),
+    ("cfg5_stage2_grouped", 1, 3840, 64, 2048, torch.bfloat16, 3),
 ]
 
 
@@ -569,7 +573,8 @@ def test_scan_full_size_properties(cfg, batch, dim, N, L, dtype, G, cuda, ops):
 
 
 @pytest.mark.parametrize("cfg,batch,dim,L,dtype", [("cfg2_stage0", 3, 128, 20480, torch.bfloat16),
-                                                   ("cfg3_stage0", 8, 128, 81920, torch.float32)])
+                                                   ("cfg3_stage0", 8, 128, 81920, torch.float32),
+                                                   ("cfg5_stage0_grouped", 1, 768, 32768, torch.bfloat16)])
 def test_conv_full_size_properties(cfg, batch, dim, L, dtype, cuda, ops):
     """Full-size conv: oracle on a channel slice; shift equivariance (delaying x by s tokens delays out
     by s tokens for a bias-free linear conv); dx is the adjoint: <conv(x), g> == <x, conv_bwd(g)>."""
