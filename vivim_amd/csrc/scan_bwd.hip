@@ -867,7 +867,7 @@ static BwdPlan bwd_plan(const vivim_ssm_fwd_params& f) {
 // the tuning selector pins one of the kernels of this file (1 / 2: fast kernel with 8 / 4 waves, 3: generic; 4 pins it).
 static bool bwd_takes_ls(const vivim_ssm_fwd_params& f) {
     const int tv = tuning_bwd_variant();
-    return ls_shape_ok(f) && scan_ckpt_len(f) == ls_ckpt_len(f) && (tv == 0 || tv == 4);
+    return ls_shape_ok(f) && scan_ckpt_len(f) == ls_ckpt_len(f) && (tv == 0 || tv == 4 || tv == 5);
 }
 
 static size_t fast_bwd_workspace_bytes(const vivim_ssm_fwd_params& f);

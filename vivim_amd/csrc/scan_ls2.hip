@@ -1,0 +1,543 @@
+// scan_ls2.hip -- selective SSM scan backward, "lanes = states" main kernel, second generation (gfx950, wave64).
+//
+// Same math and same lane mapping as ssm_ls_bwd_kernel (scan_ls.hip; reference: selective_scan_bwd_kernel.cuh:146-489):
+// a 16-lane row is one channel, the lane is the state, a tile is 16 tokens, a row walks kLsCPR channels per tile and keeps
+// their dB / dC sum in registers.  What changed is everything AROUND the two sweeps, following what round 2 measured
+// (VERDICT round 2 item 1):
+//   * activations move in SPANS of one 128-byte line per channel row (64 16-bit / 32 fp32 tokens) and 16 channels per wave:
+//     u, delta, dout, z, out are read with 16-byte vectors, whole lines at a time, once per span; du / ddelta are collected
+//     in LDS in the bytes of the u / delta tokens they were computed from and leave as whole lines too; dz -- which does
+//     not depend on the scan -- is computed and stored at span level, where a lane holds eight consecutive tokens.
+//     The first-generation kernel asked for ONE element per lane and tensor in every (tile, channel) step: 32-byte row
+//     pieces whose lines were evicted between visits (3.8 x the algorithmic traffic), ten vector-memory instructions and
+//     ~150 scalar instructions of descriptor arithmetic per step.
+//   * the per-token scalars (delta, delta * u, dy) reach the 16 lanes of a row through LDS (three ds_write_b32 by the
+//     lane that owns the token, broadcast ds_read_b128 of four tokens at a time) instead of DPP row broadcasts: a VALU
+//     instruction with a DPP operand issues at half rate and is not hidden by its neighbours (profiles/r02_valu_lab3.log),
+//     and the sweeps carried six of them per state update.
+//   * the transposed reductions are written with builtins (v_cndmask pair + one DPP add per merge): hipcc sees the DPP
+//     hazards itself, so no s_nop and free scheduling across the sweep.
+//   * dB / dC: the four rows of a wave are summed in registers (v_permlane16/32_swap merges) before they go to LDS:
+//     2 KB of slots per wave instead of 8.
+// Per wave 12.75 KB (16-bit) / 10.75 KB (fp32) of LDS: three 4-wave workgroups per CU, three waves per SIMD.
+#include "ls_common.cuh"
+
+namespace vivim {
+
+template <typename T> struct Ls2Geom {
+    static constexpr int EPV = 16 / (int)sizeof(T);      // elements per 16-byte piece
+    static constexpr int TS = 128 / (int)sizeof(T);      // tokens per span (one line per channel row)
+    static constexpr int TPS = TS / kLsT;                // tiles per span
+    // per-wave LDS block, bytes
+    static constexpr int RAWU = 0, RAWD = 2048, DY = 4096;
+    static constexpr int SCAL = DY + TS * 16 * 4;        // [row][delta | delta u | dy][16 tokens] f32
+    static constexpr int CST = SCAL + 4 * 3 * 16 * 4;    // [channel of the row][GCAR | DACC][lane] f32
+    static constexpr int SLOT = CST + kLsCPR * 2 * kWave * 4;   // [2 planes][lane][4] f32: the wave's dB / dC sums of a tile
+    static constexpr int WB = SLOT + 2 * kWave * 16;
+};
+
+// ---- 16-byte pieces <-> floats ---------------------------------------------------------------------------------------
+template <typename T> struct Ls2Piece;
+template <> struct Ls2Piece<float> {
+    static __device__ __forceinline__ void unpack(const u32x4 r, float (&v)[4]) {
+        v[0] = __uint_as_float(r.x); v[1] = __uint_as_float(r.y); v[2] = __uint_as_float(r.z); v[3] = __uint_as_float(r.w);
+    }
+    static __device__ __forceinline__ u32x4 pack(const float (&v)[4]) {
+        return u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+    }
+};
+template <> struct Ls2Piece<bf16_t> {
+    static __device__ __forceinline__ void unpack(const u32x4 r, float (&v)[8]) {
+        const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v[2 * q] = __uint_as_float(w[q] << 16); v[2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u); }
+    }
+    static __device__ __forceinline__ u32x4 pack(const float (&v)[8]) {
+        unsigned w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            union { bf16_t h[2]; unsigned u; } c;
+            c.h[0] = from_f32<bf16_t>(v[2 * q]); c.h[1] = from_f32<bf16_t>(v[2 * q + 1]);
+            w[q] = c.u;
+        }
+        return u32x4{w[0], w[1], w[2], w[3]};
+    }
+};
+template <> struct Ls2Piece<f16_t> {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ void unpack(const u32x4 r, float (&v)[8]) {
+        const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const h2 hh = __builtin_bit_cast(h2, w[q]);
+            v[2 * q] = static_cast<float>(hh.x); v[2 * q + 1] = static_cast<float>(hh.y);
+        }
+    }
+    static __device__ __forceinline__ u32x4 pack(const float (&v)[8]) {
+        unsigned w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            h2 hh; hh.x = static_cast<_Float16>(v[2 * q]); hh.y = static_cast<_Float16>(v[2 * q + 1]);
+            w[q] = __builtin_bit_cast(unsigned, hh);
+        }
+        return u32x4{w[0], w[1], w[2], w[3]};
+    }
+};
+
+// ---- transposed 16-lane reduction, compiler-visible form: each lane keeps one of the two vectors and receives the
+// other one's partner lane through ONE DPP add (the selects pair with plain VALU work, valu_lab3 pattern CP) -------------
+template <int CTRL> __device__ __forceinline__ float ls2_xchg_add(float keep, float send) {
+    return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float ls2_merge8(float X, float Y, bool hi) { return ls2_xchg_add<0x128>(hi ? Y : X, hi ? X : Y); }   // row_ror:8
+// level 4 pairs lane l with l ^ 7 (row_half_mirror, an involution like the others; a rotation by 4 is not): the partners differ
+// in bit 2, which is all the merge needs, and the four levels {8, 7, 2, 1} still generate every lane of the row
+__device__ __forceinline__ float ls2_merge4(float X, float Y, bool hi) { return ls2_xchg_add<0x141>(hi ? Y : X, hi ? X : Y); }
+__device__ __forceinline__ float ls2_merge2(float X, float Y, bool hi) { return ls2_xchg_add<0x4e>(hi ? Y : X, hi ? X : Y); }    // quad_perm:[2,3,0,1]
+__device__ __forceinline__ float ls2_merge1(float X, float Y, bool hi) { return ls2_xchg_add<0xb1>(hi ? Y : X, hi ? X : Y); }    // quad_perm:[1,0,3,2]
+// merges for a DESCENDING token loop: call after token K has been produced.  Lane r ends with the total of token bitrev4(r).
+template <int K> __device__ __forceinline__ void ls2_reduce_down(float (&s)[16], float (&z)[8], float (&w)[4], float (&v)[2], float& out, int li) {
+    if constexpr ((K & 1) == 0) z[K / 2] = ls2_merge8(s[K], s[K + 1], (li & 8) != 0);
+    if constexpr ((K & 3) == 0) w[K / 4] = ls2_merge4(z[K / 2], z[K / 2 + 1], (li & 4) != 0);
+    if constexpr ((K & 7) == 0) v[K / 8] = ls2_merge2(w[K / 4], w[K / 4 + 1], (li & 2) != 0);
+    if constexpr (K == 0) out = ls2_merge1(v[0], v[1], (li & 1) != 0);
+}
+
+// sum of two vectors over row pairs: permlane16_swap exchanges the odd rows of P with the even rows of Q, so P' + Q' holds
+// rows {P.r0 + P.r1, Q.r0 + Q.r1, P.r2 + P.r3, Q.r2 + Q.r3}
+__device__ __forceinline__ float ls2_rows16(float P, float Q) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(P), __float_as_uint(Q), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+// permlane32_swap exchanges the upper half of P with the lower half of Q: P' + Q' = {P.lo + P.hi, Q.lo + Q.hi}
+__device__ __forceinline__ float ls2_rows32(float P, float Q) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(P), __float_as_uint(Q), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+
+// keeps hipcc from hoisting the LDS reads of later token groups above this point (it clusters all twelve of a sweep
+// otherwise: 48 more live registers, spilled)
+__device__ __forceinline__ void ls2_sched_fence() { asm volatile("" ::: "memory"); }
+
+#ifndef LS2_ABL
+#define LS2_ABL 0
+#endif
+constexpr int kAbl2 = LS2_ABL;       // timing experiments only (tools/abl.sh ls2build): results are WRONG for any value but 0
+
+// WPE: waves per SIMD the register budget is cut for (3: 168 VGPRs, 2: 256).  RECOMP: the decays a_t of a tile are not kept
+// from the forward sweep but recomputed in the reverse sweep (16 registers for one more v_exp_f32 per state update).
+template <typename T, bool HAS_Z, int WPE, bool RECOMP>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) ssm_ls2_bwd_kernel(const vivim_ssm_bwd_params p, const LsSeg sg) {
+    typedef Ls2Geom<T> G2;
+    typedef Ls2Piece<T> PK;
+    constexpr int EPV = G2::EPV, TS = G2::TS, TPS = G2::TPS, NS = 16, CPR = kLsCPR;
+    const vivim_ssm_fwd_params& f = p.f;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), W = blockDim.x >> 6;
+    const int row = lane >> 4, li = lane & 15;
+    const int n = li;                                         // this lane's state
+    const int tk = br4(li);                                   // this lane's token of a tile
+    const int b = blockIdx.y, seg = blockIdx.z;
+    const int L = ls_own(f.seqlen), cpg = f.dim / f.n_groups;
+    const int cpb = W * 4 * CPR;                              // channels per workgroup
+    const int bpg = (cpg + cpb - 1) / cpb;                    // workgroups per B/C group
+    const int g = blockIdx.x / bpg;
+    const int d_end = ls_own((g + 1) * cpg);
+    const int dwave = ls_own(g * cpg + (blockIdx.x - g * bpg) * cpb + wave * 4 * CPR);   // first channel of this wave (uniform)
+    const int rowch = row * CPR;                              // this row's first channel, relative to the wave's
+    const int ntiles = (L + kLsT - 1) / kLsT;
+    const int nck = ntiles;                                   // checkpoint rows of x (16 tokens each)
+    const int tile_lo = seg * sg.seg_blocks, tile_hi = min(ntiles, tile_lo + sg.seg_blocks);
+    const int t_next = tile_hi * kLsT;                        // first token right of the segment
+    const bool single = ls_own((int)(bpg == 1)) != 0;         // this workgroup is the only contributor to its dB / dC rows
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
+    unsigned char* wb = smem2 + wave * G2::WB;
+    unsigned char* raw_u = wb + G2::RAWU;
+    unsigned char* raw_d = wb + G2::RAWD;
+    float* dyb = reinterpret_cast<float*>(wb + G2::DY);                       // [channel of the wave][TS]
+    float* scal = reinterpret_cast<float*>(wb + G2::SCAL) + row * 48;         // this row's [delta | delta u | dy][16]
+    float* cst = reinterpret_cast<float*>(wb + G2::CST) + lane;               // [channel][GCAR | DACC][lane]
+    float* slot = reinterpret_cast<float*>(wb + G2::SLOT);
+    float* ctab = reinterpret_cast<float*>(smem2 + W * G2::WB) + (wave * CPR * 4 + row) * 2;   // [wave][channel][row][D | bias]
+    unsigned char* stage = smem2 + W * G2::WB + W * CPR * 8 * 4;               // [B | C][state][16 tokens] raw, next tile
+    constexpr int PT = NS * (int)sizeof(T);                   // 16-byte pieces per tensor and tile
+    enum { GCAR = 0, DACC = 1 };
+
+    typedef vivim_ssm_bwd_params BP;
+    LsRow<T> rB, rC;
+    rB.init(LS_OFF(BP, f.B), LS_OFF(BP, f.B_batch_stride), b, g, f.B_dstate_stride, n);
+    rC.init(LS_OFF(BP, f.C), LS_OFF(BP, f.C_batch_stride), b, g, f.C_dstate_stride, n);
+    const bool softplus = ls_own((int)f.delta_softplus) != 0;
+    const bool bc_vec = ls_own(sg.bc_vec) != 0;
+    // checkpoints: this lane's state of this row's first channel, checkpoint row 0 (clamped to a valid channel)
+    const float* xrow = static_cast<const float*>(f.x) + (((int64_t)b * f.dim + min(dwave + rowch, d_end - 1)) * nck) * NS + n;
+    const int xcs = nck * NS;                                 // floats between the checkpoint rows of neighbouring channels
+
+    // ---- per-channel state ----
+    float A2r[CPR], accD[CPR], accB[CPR];
+#pragma unroll
+    for (int c = 0; c < CPR; ++c) {
+        const int d = dwave + rowch + c;
+        const bool cv = d < d_end;
+        const int dc = cv ? d : d_end - 1;
+        const float A2 = static_cast<const float*>(f.A)[dc * f.A_d_stride + n * f.A_dstate_stride] * kLog2e;
+        const float bias = f.delta_bias ? static_cast<const float*>(f.delta_bias)[dc] : 0.0f;
+        const float gin = (sg.S > 1 && cv) ? sg.gin[(((int64_t)b * f.dim + dc) * sg.S + seg) * NS + n] : 0.0f;
+        float dl_nx = 0.0f;                                   // delta of the first token right of the segment
+        if (t_next < L) {
+            const float raw = to_f32<T>(static_cast<const T*>(f.delta)[b * f.delta_batch_stride + dc * f.delta_d_stride + t_next]) + bias;
+            dl_nx = softplus ? softplus_ref(raw) : raw;
+        }
+        cst[(c * 2 + GCAR) * kWave] = gin * fast_exp2(dl_nx * A2);
+        cst[(c * 2 + DACC) * kWave] = 0.0f;
+        A2r[c] = A2; accD[c] = 0.0f; accB[c] = 0.0f;
+        ctab[c * 8 + 0] = f.D ? static_cast<const float*>(f.D)[dc] : 0.0f;      // every lane of the row writes the same value
+        ctab[c * 8 + 1] = bias;
+    }
+
+    // ---- span phases: lane = (channel lane >> 3 (+ 8), 16-byte piece lane & 7) ----
+    // (the lane's coordinates are re-derived from an opaque copy in every call: hipcc otherwise hoists the sixteen 64-bit
+    // addresses of a span out of the span loop and keeps them live across the sweeps -- spilled)
+    auto load_span = [&](int sp) __attribute__((always_inline)) {
+        const ls_kargs q = ls_fresh_kargs();
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int pc = ln >> 3, pp = ln & 7;
+        const bool want_oz = HAS_Z && ls_karg<const void*>(q, LS_OFF(BP, f.out_z)) != nullptr;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int cwi = pc + 8 * i;
+            const int d = dwave + cwi;
+            const int t = sp * TS + pp * EPV;
+            const bool pv = d < d_end && t < L;               // seqlen % EPV == 0 (host check): a piece is whole or absent
+            const bool mine = pv && (t >> 4) >= tile_lo && (t >> 4) < tile_hi;
+            const int64_t dc = min(d, d_end - 1), tc = pv ? t : 0;
+            auto ld = [&](int off_ptr, int off_bs) __attribute__((always_inline)) -> u32x4 {
+                const T* ptr = ls_karg<const T*>(q, off_ptr);
+                const int64_t bs = ls_karg<int64_t>(q, off_bs), ds = ls_karg<int64_t>(q, off_bs + 8);
+                return *reinterpret_cast<const u32x4*>(ptr + b * bs + dc * ds + tc);
+            };
+            auto st = [&](int off_ptr, int off_bs, const u32x4 v) __attribute__((always_inline)) {
+                T* ptr = ls_karg<T*>(q, off_ptr);
+                const int64_t bs = ls_karg<int64_t>(q, off_bs), ds = ls_karg<int64_t>(q, off_bs + 8);
+                if (mine) *reinterpret_cast<u32x4*>(ptr + b * bs + dc * ds + tc) = v;
+            };
+            u32x4 ru = ld(LS_OFF(BP, f.u), LS_OFF(BP, f.u_batch_stride));
+            u32x4 rd = ld(LS_OFF(BP, f.delta), LS_OFF(BP, f.delta_batch_stride));
+            const u32x4 rdo = ld(LS_OFF(BP, dout), LS_OFF(BP, dout_batch_stride));
+            float dy[EPV];
+            PK::unpack(rdo, dy);
+            if (HAS_Z) {
+                const u32x4 rz = ld(LS_OFF(BP, f.z), LS_OFF(BP, f.z_batch_stride));
+                const u32x4 ro = ld(LS_OFF(BP, f.out), LS_OFF(BP, f.out_batch_stride));
+                float zf[EPV], of[EPV], dzv[EPV], ozv[EPV];
+                PK::unpack(rz, zf);
+                PK::unpack(ro, of);
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) {
+                    const float sgm = sigmoidf_fast(zf[e]);
+                    dzv[e] = dy[e] * of[e] * sgm * (1.0f + zf[e] * (1.0f - sgm));        // bwd_kernel.cuh:186-191
+                    ozv[e] = of[e] * zf[e] * sgm;                                         // bwd_kernel.cuh:193-204
+                    dy[e] *= zf[e] * sgm;
+                }
+                st(LS_OFF(BP, dz), LS_OFF(BP, dz_batch_stride), PK::pack(dzv));
+                if (want_oz) st(LS_OFF(BP, f.out_z), LS_OFF(BP, f.out_z_batch_stride), PK::pack(ozv));
+            }
+            if (!pv) {
+                ru = u32x4{0u, 0u, 0u, 0u}; rd = ru;
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) dy[e] = 0.0f;
+            }
+            *reinterpret_cast<u32x4*>(raw_u + cwi * 128 + pp * 16) = ru;
+            *reinterpret_cast<u32x4*>(raw_d + cwi * 128 + pp * 16) = rd;
+#pragma unroll
+            for (int e = 0; e < EPV; e += 4)
+                *reinterpret_cast<float4*>(dyb + cwi * TS + pp * EPV + e) = float4{dy[e], dy[e + 1], dy[e + 2], dy[e + 3]};
+        }
+        wave_lds_fence();
+    };
+    auto store_span = [&](int sp) __attribute__((always_inline)) {
+        if constexpr (kAbl2 == 3) return;
+        wave_lds_fence();
+        const ls_kargs q = ls_fresh_kargs();
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int pc = ln >> 3, pp = ln & 7;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int cwi = pc + 8 * i;
+            const int d = dwave + cwi;
+            const int t = sp * TS + pp * EPV;
+            const bool mine = d < d_end && t < L && (t >> 4) >= tile_lo && (t >> 4) < tile_hi;
+            const u32x4 vu = *reinterpret_cast<const u32x4*>(raw_u + cwi * 128 + pp * 16);
+            const u32x4 vd = *reinterpret_cast<const u32x4*>(raw_d + cwi * 128 + pp * 16);
+            T* pu = ls_karg<T*>(q, LS_OFF(BP, du));
+            const int64_t ubs = ls_karg<int64_t>(q, LS_OFF(BP, du_batch_stride)), uds = ls_karg<int64_t>(q, LS_OFF(BP, du_d_stride));
+            T* pd = ls_karg<T*>(q, LS_OFF(BP, ddelta));
+            const int64_t dbs = ls_karg<int64_t>(q, LS_OFF(BP, ddelta_batch_stride)), dds = ls_karg<int64_t>(q, LS_OFF(BP, ddelta_d_stride));
+            if (mine) {
+                *reinterpret_cast<u32x4*>(pu + b * ubs + (int64_t)d * uds + t) = vu;
+                *reinterpret_cast<u32x4*>(pd + b * dbs + (int64_t)d * dds + t) = vd;
+            }
+        }
+        wave_lds_fence();
+    };
+
+    // the checkpoint (state at the left edge of a tile) of a step, requested one step ahead
+    auto fetch_h = [&](int tile, int c) __attribute__((always_inline)) -> float {
+        const bool v = tile > 0 && tile >= tile_lo && dwave + rowch + c < d_end;
+        return xrow[v ? c * xcs + (tile - 1) * NS : 0];
+    };
+
+    float Bv[16], Cv[16], dBv[16], dCv[16];
+    bool staged = false;
+    float hnx = fetch_h(tile_hi - 1, 0);
+
+    const int sp_hi = (tile_hi - 1) / TPS, sp_lo = tile_lo / TPS;
+#pragma unroll 1
+    for (int sp = sp_hi; sp >= sp_lo; --sp) {
+        load_span(sp);
+        const int tl_hi = min(tile_hi, (sp + 1) * TPS) - 1, tl_lo = max(tile_lo, sp * TPS);
+#pragma unroll 1
+        for (int tile = tl_hi; tile >= tl_lo; --tile) {
+            const int t0 = tile * kLsT;
+            const int t = t0 + tk;
+            const bool tv = t < L;
+            const int tok = (tile - sp * TPS) * kLsT + tk;    // this lane's token inside the span
+            if (staged) {                                     // this tile's rows were staged during the previous one
+                constexpr int NV = (int)sizeof(T);
+                u32x4 rb[NV], rc[NV];
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    rb[i] = *reinterpret_cast<const u32x4*>(stage + (n * NV + i) * 16);
+                    rc[i] = *reinterpret_cast<const u32x4*>(stage + (PT + n * NV + i) * 16);
+                }
+                LsUnpack<T>::run(rb, Bv);
+                LsUnpack<T>::run(rc, Cv);
+            } else {
+                const bool vec = bc_vec && t0 + kLsT <= L;
+                const ls_kargs q = ls_fresh_kargs();
+                rB.load16(q, t0, L, vec, Bv);
+                rC.load16(q, t0, L, vec, Cv);
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { dBv[k] = 0.0f; dCv[k] = 0.0f; }
+            const bool stage_next = W == 4 && bc_vec && tile - 1 >= tile_lo;   // (a tile left of another one is whole)
+            u32x4 sb = {0u, 0u, 0u, 0u}, sc = {0u, 0u, 0u, 0u};
+#pragma unroll 1
+            for (int c = 0; c < CPR; ++c) {
+                const int d = dwave + rowch + c;
+                const bool cv = d < d_end;                    // uniform per row
+                const bool ok = cv && tv;
+                const int cw = rowch + c;
+                float h_in = (cv && tile > 0) ? hnx : 0.0f;
+                asm volatile("" : "+v"(h_in));                // used here: before the next step's request is issued
+                hnx = fetch_h(c + 1 < CPR ? tile : tile - 1, c + 1 < CPR ? c + 1 : 0);
+                if (c == CPR - 1 && stage_next) {             // the next tile's B / C rows: one 16-byte piece of each per thread
+                    const ls_kargs q = ls_fresh_kargs();
+                    const bool mine = tid < PT;
+                    const unsigned pn = (unsigned)tid / (unsigned)sizeof(T), pq = (unsigned)tid % (unsigned)sizeof(T);
+                    sb = rB.piece(q, (tile - 1) * kLsT, mine ? pn : 0u, mine ? pq : 0u);
+                    sc = rC.piece(q, (tile - 1) * kLsT, mine ? pn : 0u, mine ? pq : 0u);
+                }
+                // ---- this lane's token of channel d ----
+                const float uu = to_f32<T>(*reinterpret_cast<const T*>(raw_u + cw * 128 + tok * (int)sizeof(T)));
+                const float raw = to_f32<T>(*reinterpret_cast<const T*>(raw_d + cw * 128 + tok * (int)sizeof(T))) + ctab[c * 8 + 1];
+                const float dy = dyb[cw * TS + tok];          // zero outside the row / the group
+                const float dl = ok ? (softplus ? softplus_ref(raw) : raw) : 0.0f;        // padded tokens: identity step
+                const float w = dl * uu;
+                scal[tk] = dl; scal[16 + tk] = w; scal[32 + tk] = dy;
+                wave_lds_fence();
+                {   // the row's four channels take turns in slot 0: a tile is exactly four steps, so the order is restored
+                    const float t0a = fmaf(dy, uu, accD[0]);
+                    accD[0] = accD[1]; accD[1] = accD[2]; accD[2] = accD[3]; accD[3] = t0a;
+                }
+                const float A2 = c == 0 ? A2r[0] : c == 1 ? A2r[1] : c == 2 ? A2r[2] : A2r[3];
+                // ---- forward states of the tile, from the checkpoint ----
+                float a[RECOMP ? 1 : 16], h[16];
+                {
+                    float hp = h_in;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        ls2_sched_fence();
+                        const float4 d4 = *reinterpret_cast<const float4*>(scal + 4 * m), w4 = *reinterpret_cast<const float4*>(scal + 16 + 4 * m);
+                        const float dd[4] = {d4.x, d4.y, d4.z, d4.w}, ww[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int k = 4 * m + j;
+                            if constexpr (kAbl2 == 6) { a[RECOMP ? 0 : k] = A2; h[k] = hp + Bv[k]; continue; }
+                            const float ak = fast_exp2(dd[j] * A2);
+                            a[RECOMP ? 0 : k] = ak;
+                            hp = fmaf(ak, hp, ww[j] * Bv[k]);                            // h_t = a_t h_{t-1} + d_t u_t B_t
+                            h[k] = hp;
+                        }
+                    }
+                }
+                // ---- reverse sweep: g_t = a_{t+1} g_{t+1} + C_t dy_t; ag = a_t g_t is the carry to the left ----
+                float s1[16], s2[16], z1[8], z2[8], w1[4], w2[4], v1[2], v2[2], S1 = 0.0f, S2 = 0.0f;
+                {
+                    float ag = cst[(c * 2 + GCAR) * kWave], dA0 = cst[(c * 2 + DACC) * kWave], dA1 = 0.0f;
+                    sfor_down<4>([&](auto mc) {
+                        constexpr int m = decltype(mc)::value;
+                        ls2_sched_fence();
+                        const float4 d4 = *reinterpret_cast<const float4*>(scal + 4 * m), w4 = *reinterpret_cast<const float4*>(scal + 16 + 4 * m),
+                                     y4 = *reinterpret_cast<const float4*>(scal + 32 + 4 * m);
+                        const float dd[4] = {d4.x, d4.y, d4.z, d4.w}, ww[4] = {w4.x, w4.y, w4.z, w4.w}, yy[4] = {y4.x, y4.y, y4.z, y4.w};
+                        sfor_down<4>([&](auto jc) {
+                            constexpr int j = decltype(jc)::value;
+                            constexpr int k = 4 * m + j;
+                            const float gk = fmaf(yy[j], Cv[k], ag);                        // g_t
+                            ag = gk * (RECOMP ? fast_exp2(dd[j] * A2) : a[RECOMP ? 0 : k]);
+                            const float x = ag * (k > 0 ? h[k > 0 ? k - 1 : 0] : h_in);    // g_t a_t h_{t-1}
+                            s1[k] = gk * Bv[k];
+                            s2[k] = A2 * x;
+                            if constexpr (k & 1) dA1 = fmaf(dd[j], x, dA1); else dA0 = fmaf(dd[j], x, dA0);   // two chains
+                            dBv[k] = fmaf(ww[j], gk, dBv[k]);
+                            dCv[k] = fmaf(yy[j], h[k], dCv[k]);
+                            if constexpr (kAbl2 == 7) { if (k == 0) { S1 = s1[0] + s1[5] + s1[15]; S2 = s2[0] + s2[7] + s2[15]; } return; }
+                            ls2_reduce_down<k>(s1, z1, w1, v1, S1, li);
+                            ls2_reduce_down<k>(s2, z2, w2, v2, S2, li);
+                        });
+                    });
+                    cst[(c * 2 + GCAR) * kWave] = ag;
+                    cst[(c * 2 + DACC) * kWave] = dA0 + dA1;
+                }
+                // ---- per-token outputs (this lane's token), into the bytes of the u / delta tokens they came from ----
+                const float duv = fmaf(dl, S1, ctab[c * 8 + 0] * dy);
+                float ddv = fmaf(uu, S1, S2 * kLn2);                                      // S2 carries A * log2e
+                if (softplus && raw <= 20.0f) ddv *= sigmoidf_fast(raw);                  // bwd_kernel.cuh:439-452
+                {
+                    const float t0b = accB[0] + (ok ? ddv : 0.0f);
+                    accB[0] = accB[1]; accB[1] = accB[2]; accB[2] = accB[3]; accB[3] = t0b;
+                }
+                *reinterpret_cast<T*>(raw_u + cw * 128 + tok * (int)sizeof(T)) = from_f32<T>(duv);
+                *reinterpret_cast<T*>(raw_d + cw * 128 + tok * (int)sizeof(T)) = from_f32<T>(ddv);
+            }
+            // ---- dB / dC of the tile: the row's channels are summed in dBv / dCv; add the four rows in registers, then the
+            // waves of the workgroup through LDS.  R[k], row r = the wave's total of vector 4 k + r (0-15 dB, 16-31 dC by token).
+            if constexpr (kAbl2 == 1) continue;
+            float R[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                R[k] = ls2_rows32(ls2_rows16(dBv[4 * k], dBv[4 * k + 1]), ls2_rows16(dBv[4 * k + 2], dBv[4 * k + 3]));
+                R[4 + k] = ls2_rows32(ls2_rows16(dCv[4 * k], dCv[4 * k + 1]), ls2_rows16(dCv[4 * k + 2], dCv[4 * k + 3]));
+            }
+            // Both barriers sit around the slot writes: "everybody is done reading the previous tile's slots and this tile's
+            // staged rows", then "slots and the next tile's rows are written".
+            lds_barrier();
+            if (stage_next && tid < PT) {
+                *reinterpret_cast<u32x4*>(stage + tid * 16) = sb;
+                *reinterpret_cast<u32x4*>(stage + (PT + tid) * 16) = sc;
+            }
+            staged = stage_next;
+            *reinterpret_cast<float4*>(slot + lane * 4) = float4{R[0], R[1], R[2], R[3]};
+            *reinterpret_cast<float4*>(slot + (kWave + lane) * 4) = float4{R[4], R[5], R[6], R[7]};
+            lds_barrier();
+            {
+                const ls_kargs q = ls_fresh_kargs();
+                float* __restrict__ dBg = ls_karg<float*>(q, LS_OFF(BP, dB)) + b * ls_karg<int64_t>(q, LS_OFF(BP, dB_batch_stride)) + g * ls_karg<int64_t>(q, LS_OFF(BP, dB_group_stride));
+                float* __restrict__ dCg = ls_karg<float*>(q, LS_OFF(BP, dC)) + b * ls_karg<int64_t>(q, LS_OFF(BP, dC_batch_stride)) + g * ls_karg<int64_t>(q, LS_OFF(BP, dC_group_stride));
+                const int dBns = (int)ls_karg<int64_t>(q, LS_OFF(BP, dB_dstate_stride)), dCns = (int)ls_karg<int64_t>(q, LS_OFF(BP, dC_dstate_stride));
+                for (int e = tid; e < 2 * NS * 16; e += blockDim.x) {
+                    const int isC = e >> 8, en = (e >> 4) & 15, ek = e & 15;
+                    const int i = isC * 16 + ek, k = i >> 2, r = i & 3;
+                    const float* sp0 = reinterpret_cast<const float*>(smem2 + G2::SLOT) + ((k >> 2) * kWave + r * 16 + en) * 4 + (k & 3);
+                    float acc = sp0[0];
+                    for (int s = 1; s < W; ++s) acc += sp0[s * (G2::WB / 4)];
+                    if (t0 + ek < L) {
+                        float* dst = isC ? dCg + en * dCns : dBg + en * dBns;
+                        if (single) dst[t0 + ek] = acc;                   // the only contributor: plain store, deterministic
+                        else atomicAdd(dst + t0 + ek, acc);
+                    }
+                }
+            }
+        }
+        store_span(sp);
+    }
+    // ---- per-channel sums ----
+#pragma unroll
+    for (int c = 0; c < CPR; ++c) {
+        const int d = dwave + rowch + c;
+        const float sD = ls_row_total(accD[c]), sbias = ls_row_total(accB[c]);
+        if (d >= d_end) continue;                             // uniform per row
+        atomicAdd(static_cast<float*>(p.dA) + d * p.dA_d_stride + n * p.dA_dstate_stride, cst[(c * 2 + DACC) * kWave]);
+        if (li == 0) {
+            if (p.dD) atomicAdd(static_cast<float*>(p.dD) + d, sD);
+            if (p.ddelta_bias) atomicAdd(static_cast<float*>(p.ddelta_bias) + d, sbias);
+        }
+    }
+}
+
+// =========================================================================================================================
+// Host side
+// =========================================================================================================================
+size_t ls2_bwd_smem(int W, int itype) {
+    const int wb = itype == VIVIM_F32 ? Ls2Geom<float>::WB : Ls2Geom<bf16_t>::WB;
+    const int es = itype == VIVIM_F32 ? 4 : 2;
+    return (size_t)W * wb + (size_t)W * kLsCPR * 8 * 4 + (size_t)2 * 16 * 16 * es;
+}
+
+// Vector path: every activation row 16-byte aligned and a whole number of 16-byte pieces long.
+bool ls2_bwd_ok(const vivim_ssm_bwd_params& p) {
+    const vivim_ssm_fwd_params& f = p.f;
+    if (f.dstate != 16 || !f.is_variable_B || !f.is_variable_C) return false;
+    const int64_t epv = f.itype == VIVIM_F32 ? 4 : 8;
+    auto al = [&](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    auto st = [&](int64_t e) { return e % epv == 0; };
+    if (f.seqlen % epv != 0 || !al(f.u) || !al(f.delta) || !al(p.dout) || !al(p.du) || !al(p.ddelta) ||
+        !st(f.u_batch_stride) || !st(f.u_d_stride) || !st(f.delta_batch_stride) || !st(f.delta_d_stride) ||
+        !st(p.dout_batch_stride) || !st(p.dout_d_stride) || !st(p.du_batch_stride) || !st(p.du_d_stride) ||
+        !st(p.ddelta_batch_stride) || !st(p.ddelta_d_stride))
+        return false;
+    if (f.z && (!al(f.z) || !al(f.out) || !al(p.dz) || !st(f.z_batch_stride) || !st(f.z_d_stride) ||
+                !st(f.out_batch_stride) || !st(f.out_d_stride) || !st(p.dz_batch_stride) || !st(p.dz_d_stride) ||
+                (f.out_z && (!al(f.out_z) || !st(f.out_z_batch_stride) || !st(f.out_z_d_stride)))))
+        return false;
+    return true;
+}
+
+template <typename T> static void ls2_launch_t(const vivim_ssm_bwd_params& p, const LsSeg& sg, int W, hipStream_t stream) {
+    const vivim_ssm_fwd_params& f = p.f;
+    const int cpg = f.dim / f.n_groups;
+    const int cpb = W * 4 * kLsCPR;
+    const int bpg = (cpg + cpb - 1) / cpb;
+    const dim3 grid(bpg * f.n_groups, f.batch, sg.S);
+    const size_t smem = ls2_bwd_smem(W, f.itype);
+    auto launch = [&](auto kernel) {
+        if (smem > 65536)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(kernel, grid, dim3(W * kWave), smem, stream, p, sg);
+    };
+    if (f.z) launch(ssm_ls2_bwd_kernel<T, true, 2, false>); else launch(ssm_ls2_bwd_kernel<T, false, 2, false>);
+}
+
+void ls2_bwd_launch(const vivim_ssm_bwd_params& p, const LsSeg& sg, int W, hipStream_t stream) {
+    switch (p.f.itype) {
+        case VIVIM_F32: ls2_launch_t<float>(p, sg, W, stream); break;
+        case VIVIM_F16: ls2_launch_t<f16_t>(p, sg, W, stream); break;
+        case VIVIM_BF16: ls2_launch_t<bf16_t>(p, sg, W, stream); break;
+    }
+}
+
+int ls2_bwd_blocks_per_cu(int itype, bool has_z, int W) {
+    int nb = 0;
+    const size_t smem = ls2_bwd_smem(W, itype);
+    hipError_t e = hipSuccess;
+    auto q = [&](auto kernel) {
+        if (smem > 65536)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, W * kWave, smem);
+    };
+    auto by_t = [&](auto tag) {
+        typedef decltype(tag) T;
+        if (has_z) q(ssm_ls2_bwd_kernel<T, true, 2, false>); else q(ssm_ls2_bwd_kernel<T, false, 2, false>);
+    };
+    if (itype == VIVIM_F32) by_t(float{}); else if (itype == VIVIM_F16) by_t(f16_t{}); else by_t(bf16_t{});
+    if (e != hipSuccess || nb <= 0) { (void)hipGetLastError(); nb = 2; }
+    return nb;
+}
+
+}  // namespace vivim
