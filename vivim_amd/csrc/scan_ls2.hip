@@ -29,10 +29,9 @@ template <typename T> struct Ls2Geom {
     static constexpr int TS = 128 / (int)sizeof(T);      // tokens per span (one line per channel row)
     static constexpr int TPS = TS / kLsT;                // tiles per span
     // per-wave LDS block, bytes
-    static constexpr int RAWU = 0, RAWD = 2048, DY = 4096;
-    static constexpr int SCAL = DY + TS * 16 * 4;        // [row][delta | delta u | dy][16 tokens] f32
-    static constexpr int CST = SCAL + 4 * 3 * 16 * 4;    // [channel of the row][GCAR | DACC][lane] f32
-    static constexpr int SLOT = CST + kLsCPR * 2 * kWave * 4;   // [2 planes][lane][4] f32: the wave's dB / dC sums of a tile
+    static constexpr int RAWU = 0, RAWD = 2048, DL = 4096;
+    static constexpr int WU = DL + TS * 16 * 4, DY = WU + TS * 16 * 4;
+    static constexpr int SLOT = DY + TS * 16 * 4;       // [2 planes][lane][4] f32: the wave's dB / dC sums of a tile
     static constexpr int WB = SLOT + 2 * kWave * 16;
 };
 
@@ -126,10 +125,12 @@ __device__ __forceinline__ void ls2_sched_fence() { asm volatile("" ::: "memory"
 #endif
 constexpr int kAbl2 = LS2_ABL;       // timing experiments only (tools/abl.sh ls2build): results are WRONG for any value but 0
 
-// WPE: waves per SIMD the register budget is cut for (3: 168 VGPRs, 2: 256).  RECOMP: the decays a_t of a tile are not kept
-// from the forward sweep but recomputed in the reverse sweep (16 registers for one more v_exp_f32 per state update).
-template <typename T, bool HAS_Z, int WPE, bool RECOMP>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) ssm_ls2_bwd_kernel(const vivim_ssm_bwd_params p, const LsSeg sg) {
+// One (tile, channel) step is the forward sweep, the reverse sweep and four instructions of output arithmetic: everything a
+// token needs that does not depend on the scan (softplus, the z gate, dz, the sigmoid factor of ddelta) is done at SPAN
+// level, where a lane holds EPV consecutive tokens of one channel and their dependency chains interleave -- in-kernel
+// stamps of the first build had a step spend 1000 + 600 cycles of pure latency in these chains against 2700 in the sweeps.
+template <typename T, bool HAS_Z>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) ssm_ls2_bwd_kernel(const vivim_ssm_bwd_params p, const LsSeg sg) {
     typedef Ls2Geom<T> G2;
     typedef Ls2Piece<T> PK;
     constexpr int EPV = G2::EPV, TS = G2::TS, TPS = G2::TPS, NS = 16, CPR = kLsCPR;
@@ -155,16 +156,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, W
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
     unsigned char* wb = smem2 + wave * G2::WB;
-    unsigned char* raw_u = wb + G2::RAWU;
-    unsigned char* raw_d = wb + G2::RAWD;
-    float* dyb = reinterpret_cast<float*>(wb + G2::DY);                       // [channel of the wave][TS]
-    float* scal = reinterpret_cast<float*>(wb + G2::SCAL) + row * 48;         // this row's [delta | delta u | dy][16]
-    float* cst = reinterpret_cast<float*>(wb + G2::CST) + lane;               // [channel][GCAR | DACC][lane]
+    unsigned char* raw_u = wb + G2::RAWU;                     // [channel of the wave][128 bytes]: u as loaded
+    unsigned char* raw_d = wb + G2::RAWD;                     // delta as loaded
+    float* dlb = reinterpret_cast<float*>(wb + G2::DL);       // [channel][TS] f32: delta after softplus
+    float* wub = reinterpret_cast<float*>(wb + G2::WU);       // delta * u; after a token's step: its du
+    float* dyb = reinterpret_cast<float*>(wb + G2::DY);       // dy (gated dout); after a token's step: its ddelta before the sigmoid factor
     float* slot = reinterpret_cast<float*>(wb + G2::SLOT);
-    float* ctab = reinterpret_cast<float*>(smem2 + W * G2::WB) + (wave * CPR * 4 + row) * 2;   // [wave][channel][row][D | bias]
+    float* ctab = reinterpret_cast<float*>(smem2 + W * G2::WB) + (wave * CPR * 4 + row) * 2;   // [wave][channel][row][D | -]
     unsigned char* stage = smem2 + W * G2::WB + W * CPR * 8 * 4;               // [B | C][state][16 tokens] raw, next tile
     constexpr int PT = NS * (int)sizeof(T);                   // 16-byte pieces per tensor and tile
-    enum { GCAR = 0, DACC = 1 };
 
     typedef vivim_ssm_bwd_params BP;
     LsRow<T> rB, rC;
@@ -176,8 +176,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, W
     const float* xrow = static_cast<const float*>(f.x) + (((int64_t)b * f.dim + min(dwave + rowch, d_end - 1)) * nck) * NS + n;
     const int xcs = nck * NS;                                 // floats between the checkpoint rows of neighbouring channels
 
-    // ---- per-channel state ----
-    float A2r[CPR], accD[CPR], accB[CPR];
+    // ---- per-channel state of the row's channels: A * log2e, the reverse carry a_{t+1} g_{t+1}, the running dA.  The four
+    // channels take turns in slot 0 (a tile is exactly four steps, so the order is restored at every tile edge) ----
+    float A2r[CPR], gcar[CPR], dacc[CPR];
 #pragma unroll
     for (int c = 0; c < CPR; ++c) {
         const int d = dwave + rowch + c;
@@ -191,16 +192,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, W
             const float raw = to_f32<T>(static_cast<const T*>(f.delta)[b * f.delta_batch_stride + dc * f.delta_d_stride + t_next]) + bias;
             dl_nx = softplus ? softplus_ref(raw) : raw;
         }
-        cst[(c * 2 + GCAR) * kWave] = gin * fast_exp2(dl_nx * A2);
-        cst[(c * 2 + DACC) * kWave] = 0.0f;
-        A2r[c] = A2; accD[c] = 0.0f; accB[c] = 0.0f;
+        gcar[c] = gin * fast_exp2(dl_nx * A2);
+        dacc[c] = 0.0f;
+        A2r[c] = A2;
         ctab[c * 8 + 0] = f.D ? static_cast<const float*>(f.D)[dc] : 0.0f;      // every lane of the row writes the same value
-        ctab[c * 8 + 1] = bias;
     }
-
-    // ---- span phases: lane = (channel lane >> 3 (+ 8), 16-byte piece lane & 7) ----
+    // ---- span level: lane = (channel (lane >> 3) + 8 i, 16-byte piece lane & 7) ----
+    float bias2[2], accD2[2] = {0.0f, 0.0f}, accB2[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int d = min(dwave + (lane >> 3) + 8 * i, d_end - 1);
+        bias2[i] = f.delta_bias ? static_cast<const float*>(f.delta_bias)[d] : 0.0f;
+    }
     // (the lane's coordinates are re-derived from an opaque copy in every call: hipcc otherwise hoists the sixteen 64-bit
-    // addresses of a span out of the span loop and keeps them live across the sweeps -- spilled)
+    // addresses of a span out of the span loop and keeps them live across the sweeps)
     auto load_span = [&](int sp) __attribute__((always_inline)) {
         const ls_kargs q = ls_fresh_kargs();
         int ln = lane;
@@ -225,11 +230,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, W
                 const int64_t bs = ls_karg<int64_t>(q, off_bs), ds = ls_karg<int64_t>(q, off_bs + 8);
                 if (mine) *reinterpret_cast<u32x4*>(ptr + b * bs + dc * ds + tc) = v;
             };
-            u32x4 ru = ld(LS_OFF(BP, f.u), LS_OFF(BP, f.u_batch_stride));
-            u32x4 rd = ld(LS_OFF(BP, f.delta), LS_OFF(BP, f.delta_batch_stride));
+            const u32x4 ru = ld(LS_OFF(BP, f.u), LS_OFF(BP, f.u_batch_stride));
+            const u32x4 rd = ld(LS_OFF(BP, f.delta), LS_OFF(BP, f.delta_batch_stride));
             const u32x4 rdo = ld(LS_OFF(BP, dout), LS_OFF(BP, dout_batch_stride));
-            float dy[EPV];
+            float dy[EPV], uu[EPV], dl[EPV], wu[EPV];
             PK::unpack(rdo, dy);
+            PK::unpack(ru, uu);
+            PK::unpack(rd, dl);
             if (HAS_Z) {
                 const u32x4 rz = ld(LS_OFF(BP, f.z), LS_OFF(BP, f.z_batch_stride));
                 const u32x4 ro = ld(LS_OFF(BP, f.out), LS_OFF(BP, f.out_batch_stride));
@@ -246,16 +253,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, W
                 st(LS_OFF(BP, dz), LS_OFF(BP, dz_batch_stride), PK::pack(dzv));
                 if (want_oz) st(LS_OFF(BP, f.out_z), LS_OFF(BP, f.out_z_batch_stride), PK::pack(ozv));
             }
-            if (!pv) {
-                ru = u32x4{0u, 0u, 0u, 0u}; rd = ru;
+            float sD = 0.0f;
 #pragma unroll
-                for (int e = 0; e < EPV; ++e) dy[e] = 0.0f;
+            for (int e = 0; e < EPV; ++e) {
+                const float raw = dl[e] + bias2[i];
+                dl[e] = pv ? (softplus ? softplus_ref(raw) : raw) : 0.0f;                 // absent tokens: identity steps
+                dy[e] = pv ? dy[e] : 0.0f;
+                wu[e] = dl[e] * uu[e];
+                sD = fmaf(dy[e], uu[e], sD);
             }
+            accD2[i] += mine ? sD : 0.0f;
             *reinterpret_cast<u32x4*>(raw_u + cwi * 128 + pp * 16) = ru;
             *reinterpret_cast<u32x4*>(raw_d + cwi * 128 + pp * 16) = rd;
 #pragma unroll
-            for (int e = 0; e < EPV; e += 4)
+            for (int e = 0; e < EPV; e += 4) {
+                *reinterpret_cast<float4*>(dlb + cwi * TS + pp * EPV + e) = float4{dl[e], dl[e + 1], dl[e + 2], dl[e + 3]};
+                *reinterpret_cast<float4*>(wub + cwi * TS + pp * EPV + e) = float4{wu[e], wu[e + 1], wu[e + 2], wu[e + 3]};
                 *reinterpret_cast<float4*>(dyb + cwi * TS + pp * EPV + e) = float4{dy[e], dy[e + 1], dy[e + 2], dy[e + 3]};
+            }
         }
         wave_lds_fence();
     };
@@ -272,29 +287,57 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, W
             const int d = dwave + cwi;
             const int t = sp * TS + pp * EPV;
             const bool mine = d < d_end && t < L && (t >> 4) >= tile_lo && (t >> 4) < tile_hi;
-            const u32x4 vu = *reinterpret_cast<const u32x4*>(raw_u + cwi * 128 + pp * 16);
-            const u32x4 vd = *reinterpret_cast<const u32x4*>(raw_d + cwi * 128 + pp * 16);
+            float du[EPV], dd[EPV], raw[EPV];
+            PK::unpack(*reinterpret_cast<const u32x4*>(raw_d + cwi * 128 + pp * 16), raw);
+#pragma unroll
+            for (int e = 0; e < EPV; e += 4) {
+                const float4 a4 = *reinterpret_cast<const float4*>(wub + cwi * TS + pp * EPV + e);
+                const float4 b4 = *reinterpret_cast<const float4*>(dyb + cwi * TS + pp * EPV + e);
+                du[e] = a4.x; du[e + 1] = a4.y; du[e + 2] = a4.z; du[e + 3] = a4.w;
+                dd[e] = b4.x; dd[e + 1] = b4.y; dd[e + 2] = b4.z; dd[e + 3] = b4.w;
+            }
+            float sB = 0.0f;
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                const float r = raw[e] + bias2[i];
+                if (softplus) dd[e] *= r <= 20.0f ? sigmoidf_fast(r) : 1.0f;              // bwd_kernel.cuh:439-452
+                sB += dd[e];
+            }
+            accB2[i] += mine ? sB : 0.0f;
             T* pu = ls_karg<T*>(q, LS_OFF(BP, du));
             const int64_t ubs = ls_karg<int64_t>(q, LS_OFF(BP, du_batch_stride)), uds = ls_karg<int64_t>(q, LS_OFF(BP, du_d_stride));
             T* pd = ls_karg<T*>(q, LS_OFF(BP, ddelta));
             const int64_t dbs = ls_karg<int64_t>(q, LS_OFF(BP, ddelta_batch_stride)), dds = ls_karg<int64_t>(q, LS_OFF(BP, ddelta_d_stride));
             if (mine) {
-                *reinterpret_cast<u32x4*>(pu + b * ubs + (int64_t)d * uds + t) = vu;
-                *reinterpret_cast<u32x4*>(pd + b * dbs + (int64_t)d * dds + t) = vd;
+                *reinterpret_cast<u32x4*>(pu + b * ubs + (int64_t)d * uds + t) = PK::pack(du);
+                *reinterpret_cast<u32x4*>(pd + b * dbs + (int64_t)d * dds + t) = PK::pack(dd);
             }
         }
         wave_lds_fence();
     };
 
-    // the checkpoint (state at the left edge of a tile) of a step, requested one step ahead
-    auto fetch_h = [&](int tile, int c) __attribute__((always_inline)) -> float {
-        const bool v = tile > 0 && tile >= tile_lo && dwave + rowch + c < d_end;
-        return xrow[v ? c * xcs + (tile - 1) * NS : 0];
+    // The checkpoints (state at the left edge of a tile) of the row's four channels are requested a whole tile ahead and taken
+    // out of the memory queue BEFORE that tile's dB / dC atomics are issued: the queue completes in order, so a load that is
+    // waited for behind an atomic waits for the atomic (~3000 cycles with every CU adding).  The step loop itself then
+    // contains no vector-memory wait at all.
+    auto fetch_h = [&](int tile, float (&hn)[CPR]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < CPR; ++c) {
+            const bool v = tile > 0 && tile >= tile_lo && dwave + rowch + c < d_end;
+            hn[c] = xrow[v ? c * xcs + (tile - 1) * NS : 0];
+        }
     };
 
     float Bv[16], Cv[16], dBv[16], dCv[16];
     bool staged = false;
-    float hnx = fetch_h(tile_hi - 1, 0);
+    float hcur[CPR], hnxt[CPR];
+    fetch_h(tile_hi - 1, hcur);
+#ifdef VIVIM_STAMPS
+    int stamp_step = 0;                                       // DIAGNOSTIC builds only (tools/ls2_lab.hip)
+#define LS2_STAMP(slot) VIVIM_STAMP(stamp_step, slot, wave, lane)
+#else
+#define LS2_STAMP(slot) ((void)0)
+#endif
 
     const int sp_hi = (tile_hi - 1) / TPS, sp_lo = tile_lo / TPS;
 #pragma unroll 1
@@ -304,9 +347,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, W
 #pragma unroll 1
         for (int tile = tl_hi; tile >= tl_lo; --tile) {
             const int t0 = tile * kLsT;
-            const int t = t0 + tk;
-            const bool tv = t < L;
-            const int tok = (tile - sp * TPS) * kLsT + tk;    // this lane's token inside the span
+            const int tokb = (tile - sp * TPS) * kLsT;        // the tile's first token inside the span
             if (staged) {                                     // this tile's rows were staged during the previous one
                 constexpr int NV = (int)sizeof(T);
                 u32x4 rb[NV], rc[NV];
@@ -327,15 +368,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, W
             for (int k = 0; k < 16; ++k) { dBv[k] = 0.0f; dCv[k] = 0.0f; }
             const bool stage_next = W == 4 && bc_vec && tile - 1 >= tile_lo;   // (a tile left of another one is whole)
             u32x4 sb = {0u, 0u, 0u, 0u}, sc = {0u, 0u, 0u, 0u};
+            fetch_h(tile - 1, hnxt);
 #pragma unroll 1
             for (int c = 0; c < CPR; ++c) {
                 const int d = dwave + rowch + c;
                 const bool cv = d < d_end;                    // uniform per row
-                const bool ok = cv && tv;
                 const int cw = rowch + c;
-                float h_in = (cv && tile > 0) ? hnx : 0.0f;
-                asm volatile("" : "+v"(h_in));                // used here: before the next step's request is issued
-                hnx = fetch_h(c + 1 < CPR ? tile : tile - 1, c + 1 < CPR ? c + 1 : 0);
+                const float h_in = (cv && tile > 0) ? hcur[0] : 0.0f;
+                hcur[0] = hcur[1]; hcur[1] = hcur[2]; hcur[2] = hcur[3];          // the next channel moves into slot 0
                 if (c == CPR - 1 && stage_next) {             // the next tile's B / C rows: one 16-byte piece of each per thread
                     const ls_kargs q = ls_fresh_kargs();
                     const bool mine = tid < PT;
@@ -343,54 +383,50 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, W
                     sb = rB.piece(q, (tile - 1) * kLsT, mine ? pn : 0u, mine ? pq : 0u);
                     sc = rC.piece(q, (tile - 1) * kLsT, mine ? pn : 0u, mine ? pq : 0u);
                 }
-                // ---- this lane's token of channel d ----
-                const float uu = to_f32<T>(*reinterpret_cast<const T*>(raw_u + cw * 128 + tok * (int)sizeof(T)));
-                const float raw = to_f32<T>(*reinterpret_cast<const T*>(raw_d + cw * 128 + tok * (int)sizeof(T))) + ctab[c * 8 + 1];
-                const float dy = dyb[cw * TS + tok];          // zero outside the row / the group
-                const float dl = ok ? (softplus ? softplus_ref(raw) : raw) : 0.0f;        // padded tokens: identity step
-                const float w = dl * uu;
-                scal[tk] = dl; scal[16 + tk] = w; scal[32 + tk] = dy;
-                wave_lds_fence();
-                {   // the row's four channels take turns in slot 0: a tile is exactly four steps, so the order is restored
-                    const float t0a = fmaf(dy, uu, accD[0]);
-                    accD[0] = accD[1]; accD[1] = accD[2]; accD[2] = accD[3]; accD[3] = t0a;
-                }
-                const float A2 = c == 0 ? A2r[0] : c == 1 ? A2r[1] : c == 2 ? A2r[2] : A2r[3];
+                LS2_STAMP(0);
+                const float* dlr = dlb + cw * TS + tokb;      // the 16 tokens of this step: the same address in all lanes of a row
+                float* wur = wub + cw * TS + tokb;
+                float* dyr = dyb + cw * TS + tokb;
+                // this lane's own token (for the outputs): requested now, used after the sweeps
+                const float dl_t = dlr[tk], dy_t = dyr[tk];
+                const float uu = to_f32<T>(*reinterpret_cast<const T*>(raw_u + cw * 128 + (tokb + tk) * (int)sizeof(T)));
+                const float A2 = A2r[0];
+                LS2_STAMP(1);
                 // ---- forward states of the tile, from the checkpoint ----
-                float a[RECOMP ? 1 : 16], h[16];
+                float a[16], h[16];
                 {
                     float hp = h_in;
 #pragma unroll
                     for (int m = 0; m < 4; ++m) {
                         ls2_sched_fence();
-                        const float4 d4 = *reinterpret_cast<const float4*>(scal + 4 * m), w4 = *reinterpret_cast<const float4*>(scal + 16 + 4 * m);
+                        const float4 d4 = *reinterpret_cast<const float4*>(dlr + 4 * m), w4 = *reinterpret_cast<const float4*>(wur + 4 * m);
                         const float dd[4] = {d4.x, d4.y, d4.z, d4.w}, ww[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const int k = 4 * m + j;
-                            if constexpr (kAbl2 == 6) { a[RECOMP ? 0 : k] = A2; h[k] = hp + Bv[k]; continue; }
-                            const float ak = fast_exp2(dd[j] * A2);
-                            a[RECOMP ? 0 : k] = ak;
-                            hp = fmaf(ak, hp, ww[j] * Bv[k]);                            // h_t = a_t h_{t-1} + d_t u_t B_t
+                            if constexpr (kAbl2 == 6) { a[k] = A2; h[k] = hp + Bv[k]; continue; }
+                            a[k] = fast_exp2(dd[j] * A2);
+                            hp = fmaf(a[k], hp, ww[j] * Bv[k]);                          // h_t = a_t h_{t-1} + d_t u_t B_t
                             h[k] = hp;
                         }
                     }
                 }
+                LS2_STAMP(2);
                 // ---- reverse sweep: g_t = a_{t+1} g_{t+1} + C_t dy_t; ag = a_t g_t is the carry to the left ----
                 float s1[16], s2[16], z1[8], z2[8], w1[4], w2[4], v1[2], v2[2], S1 = 0.0f, S2 = 0.0f;
                 {
-                    float ag = cst[(c * 2 + GCAR) * kWave], dA0 = cst[(c * 2 + DACC) * kWave], dA1 = 0.0f;
+                    float ag = gcar[0], dA0 = dacc[0], dA1 = 0.0f;
                     sfor_down<4>([&](auto mc) {
                         constexpr int m = decltype(mc)::value;
                         ls2_sched_fence();
-                        const float4 d4 = *reinterpret_cast<const float4*>(scal + 4 * m), w4 = *reinterpret_cast<const float4*>(scal + 16 + 4 * m),
-                                     y4 = *reinterpret_cast<const float4*>(scal + 32 + 4 * m);
+                        const float4 d4 = *reinterpret_cast<const float4*>(dlr + 4 * m), w4 = *reinterpret_cast<const float4*>(wur + 4 * m),
+                                     y4 = *reinterpret_cast<const float4*>(dyr + 4 * m);
                         const float dd[4] = {d4.x, d4.y, d4.z, d4.w}, ww[4] = {w4.x, w4.y, w4.z, w4.w}, yy[4] = {y4.x, y4.y, y4.z, y4.w};
                         sfor_down<4>([&](auto jc) {
                             constexpr int j = decltype(jc)::value;
                             constexpr int k = 4 * m + j;
                             const float gk = fmaf(yy[j], Cv[k], ag);                        // g_t
-                            ag = gk * (RECOMP ? fast_exp2(dd[j] * A2) : a[RECOMP ? 0 : k]);
+                            ag = gk * a[k];
                             const float x = ag * (k > 0 ? h[k > 0 ? k - 1 : 0] : h_in);    // g_t a_t h_{t-1}
                             s1[k] = gk * Bv[k];
                             s2[k] = A2 * x;
@@ -402,23 +438,26 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, W
                             ls2_reduce_down<k>(s2, z2, w2, v2, S2, li);
                         });
                     });
-                    cst[(c * 2 + GCAR) * kWave] = ag;
-                    cst[(c * 2 + DACC) * kWave] = dA0 + dA1;
+                    // the next channel moves into slot 0
+                    gcar[0] = gcar[1]; gcar[1] = gcar[2]; gcar[2] = gcar[3]; gcar[3] = ag;
+                    dacc[0] = dacc[1]; dacc[1] = dacc[2]; dacc[2] = dacc[3]; dacc[3] = dA0 + dA1;
+                    A2r[0] = A2r[1]; A2r[1] = A2r[2]; A2r[2] = A2r[3]; A2r[3] = A2;
                 }
-                // ---- per-token outputs (this lane's token), into the bytes of the u / delta tokens they came from ----
-                const float duv = fmaf(dl, S1, ctab[c * 8 + 0] * dy);
-                float ddv = fmaf(uu, S1, S2 * kLn2);                                      // S2 carries A * log2e
-                if (softplus && raw <= 20.0f) ddv *= sigmoidf_fast(raw);                  // bwd_kernel.cuh:439-452
-                {
-                    const float t0b = accB[0] + (ok ? ddv : 0.0f);
-                    accB[0] = accB[1]; accB[1] = accB[2]; accB[2] = accB[3]; accB[3] = t0b;
-                }
-                *reinterpret_cast<T*>(raw_u + cw * 128 + tok * (int)sizeof(T)) = from_f32<T>(duv);
-                *reinterpret_cast<T*>(raw_d + cw * 128 + tok * (int)sizeof(T)) = from_f32<T>(ddv);
+                LS2_STAMP(3);
+                // ---- this lane's token: du, and ddelta up to the sigmoid factor (applied at span level), into the delta u / dy
+                // slots of the token (all sixteen were consumed by the sweeps above) ----
+                wave_lds_fence();
+                wur[tk] = fmaf(dl_t, S1, ctab[c * 8 + 0] * dy_t);
+                dyr[tk] = fmaf(uu, S1, S2 * kLn2);                                        // S2 carries A * log2e
+                LS2_STAMP(4);
+#ifdef VIVIM_STAMPS
+                if (c < CPR - 1) ++stamp_step;
+#endif
             }
             // ---- dB / dC of the tile: the row's channels are summed in dBv / dCv; add the four rows in registers, then the
             // waves of the workgroup through LDS.  R[k], row r = the wave's total of vector 4 k + r (0-15 dB, 16-31 dC by token).
             if constexpr (kAbl2 == 1) continue;
+            LS2_STAMP(5);
             float R[8];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -427,7 +466,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, W
             }
             // Both barriers sit around the slot writes: "everybody is done reading the previous tile's slots and this tile's
             // staged rows", then "slots and the next tile's rows are written".
+            LS2_STAMP(6);
             lds_barrier();
+            LS2_STAMP(7);
             if (stage_next && tid < PT) {
                 *reinterpret_cast<u32x4*>(stage + tid * 16) = sb;
                 *reinterpret_cast<u32x4*>(stage + (PT + tid) * 16) = sc;
@@ -436,24 +477,50 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, W
             *reinterpret_cast<float4*>(slot + lane * 4) = float4{R[0], R[1], R[2], R[3]};
             *reinterpret_cast<float4*>(slot + (kWave + lane) * 4) = float4{R[4], R[5], R[6], R[7]};
             lds_barrier();
+            LS2_STAMP(8);
+            // the next tile's checkpoints: out of the memory queue before this tile's atomics go in
+            asm volatile("" : "+v"(hnxt[0]), "+v"(hnxt[1]), "+v"(hnxt[2]), "+v"(hnxt[3]));
+#pragma unroll
+            for (int c = 0; c < CPR; ++c) hcur[c] = hnxt[c];
             {
                 const ls_kargs q = ls_fresh_kargs();
                 float* __restrict__ dBg = ls_karg<float*>(q, LS_OFF(BP, dB)) + b * ls_karg<int64_t>(q, LS_OFF(BP, dB_batch_stride)) + g * ls_karg<int64_t>(q, LS_OFF(BP, dB_group_stride));
                 float* __restrict__ dCg = ls_karg<float*>(q, LS_OFF(BP, dC)) + b * ls_karg<int64_t>(q, LS_OFF(BP, dC_batch_stride)) + g * ls_karg<int64_t>(q, LS_OFF(BP, dC_group_stride));
                 const int dBns = (int)ls_karg<int64_t>(q, LS_OFF(BP, dB_dstate_stride)), dCns = (int)ls_karg<int64_t>(q, LS_OFF(BP, dC_dstate_stride));
-                for (int e = tid; e < 2 * NS * 16; e += blockDim.x) {
+                auto slot_of = [&](int e) __attribute__((always_inline)) -> const float* {
                     const int isC = e >> 8, en = (e >> 4) & 15, ek = e & 15;
                     const int i = isC * 16 + ek, k = i >> 2, r = i & 3;
-                    const float* sp0 = reinterpret_cast<const float*>(smem2 + G2::SLOT) + ((k >> 2) * kWave + r * 16 + en) * 4 + (k & 3);
-                    float acc = sp0[0];
-                    for (int s = 1; s < W; ++s) acc += sp0[s * (G2::WB / 4)];
+                    return reinterpret_cast<const float*>(smem2 + G2::SLOT) + ((k >> 2) * kWave + r * 16 + en) * 4 + (k & 3);
+                };
+                auto emit = [&](int e, float acc) __attribute__((always_inline)) {
+                    const int isC = e >> 8, en = (e >> 4) & 15, ek = e & 15;
                     if (t0 + ek < L) {
                         float* dst = isC ? dCg + en * dCns : dBg + en * dBns;
                         if (single) dst[t0 + ek] = acc;                   // the only contributor: plain store, deterministic
                         else atomicAdd(dst + t0 + ek, acc);
                     }
+                };
+                if (W == 4) {                                 // two outputs per thread, their eight slot reads in flight together
+                    const float* p0 = slot_of(tid);
+                    const float* p1 = slot_of(tid + 256);
+                    constexpr int WS = G2::WB / 4;
+                    const float a0 = p0[0], a1 = p0[WS], a2 = p0[2 * WS], a3 = p0[3 * WS];
+                    const float b0 = p1[0], b1 = p1[WS], b2 = p1[2 * WS], b3 = p1[3 * WS];
+                    emit(tid, (a0 + a1) + (a2 + a3));
+                    emit(tid + 256, (b0 + b1) + (b2 + b3));
+                } else {
+                    for (int e = tid; e < 2 * NS * 16; e += blockDim.x) {
+                        const float* sp0 = slot_of(e);
+                        float acc = sp0[0];
+                        for (int s = 1; s < W; ++s) acc += sp0[s * (G2::WB / 4)];
+                        emit(e, acc);
+                    }
                 }
             }
+            LS2_STAMP(9);
+#ifdef VIVIM_STAMPS
+            ++stamp_step;
+#endif
         }
         store_span(sp);
     }
@@ -461,12 +528,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, W
 #pragma unroll
     for (int c = 0; c < CPR; ++c) {
         const int d = dwave + rowch + c;
-        const float sD = ls_row_total(accD[c]), sbias = ls_row_total(accB[c]);
         if (d >= d_end) continue;                             // uniform per row
-        atomicAdd(static_cast<float*>(p.dA) + d * p.dA_d_stride + n * p.dA_dstate_stride, cst[(c * 2 + DACC) * kWave]);
-        if (li == 0) {
+        atomicAdd(static_cast<float*>(p.dA) + d * p.dA_d_stride + n * p.dA_dstate_stride, dacc[c]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                             // dD, dbias: the eight lanes that share a channel at span level
+        float sD = accD2[i], sBs = accB2[i];
+        sD += dpp_mov<0xb1>(0.0f, sD);   sBs += dpp_mov<0xb1>(0.0f, sBs);      // lane ^ 1
+        sD += dpp_mov<0x4e>(0.0f, sD);   sBs += dpp_mov<0x4e>(0.0f, sBs);      // lane ^ 2
+        sD += dpp_mov<0x141>(0.0f, sD);  sBs += dpp_mov<0x141>(0.0f, sBs);     // lane ^ 7 (row_half_mirror): the other quad
+        const int d = dwave + (lane >> 3) + 8 * i;
+        if ((lane & 7) == 0 && d < d_end) {
             if (p.dD) atomicAdd(static_cast<float*>(p.dD) + d, sD);
-            if (p.ddelta_bias) atomicAdd(static_cast<float*>(p.ddelta_bias) + d, sbias);
+            if (p.ddelta_bias) atomicAdd(static_cast<float*>(p.ddelta_bias) + d, sBs);
         }
     }
 }
@@ -477,7 +551,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, W
 size_t ls2_bwd_smem(int W, int itype) {
     const int wb = itype == VIVIM_F32 ? Ls2Geom<float>::WB : Ls2Geom<bf16_t>::WB;
     const int es = itype == VIVIM_F32 ? 4 : 2;
-    return (size_t)W * wb + (size_t)W * kLsCPR * 8 * 4 + (size_t)2 * 16 * 16 * es;
+    static const size_t pad = getenv("VIVIM_LS2_SMEM_PAD") ? (size_t)atoi(getenv("VIVIM_LS2_SMEM_PAD")) : 0;   // occupancy experiments
+    return (size_t)W * wb + (size_t)W * kLsCPR * 8 * 4 + (size_t)2 * 16 * 16 * es + pad;
 }
 
 // Vector path: every activation row 16-byte aligned and a whole number of 16-byte pieces long.
@@ -511,7 +586,7 @@ template <typename T> static void ls2_launch_t(const vivim_ssm_bwd_params& p, co
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(kernel, grid, dim3(W * kWave), smem, stream, p, sg);
     };
-    if (f.z) launch(ssm_ls2_bwd_kernel<T, true, 2, false>); else launch(ssm_ls2_bwd_kernel<T, false, 2, false>);
+    if (f.z) launch(ssm_ls2_bwd_kernel<T, true>); else launch(ssm_ls2_bwd_kernel<T, false>);
 }
 
 void ls2_bwd_launch(const vivim_ssm_bwd_params& p, const LsSeg& sg, int W, hipStream_t stream) {
@@ -533,7 +608,7 @@ int ls2_bwd_blocks_per_cu(int itype, bool has_z, int W) {
     };
     auto by_t = [&](auto tag) {
         typedef decltype(tag) T;
-        if (has_z) q(ssm_ls2_bwd_kernel<T, true, 2, false>); else q(ssm_ls2_bwd_kernel<T, false, 2, false>);
+        if (has_z) q(ssm_ls2_bwd_kernel<T, true>); else q(ssm_ls2_bwd_kernel<T, false>);
     };
     if (itype == VIVIM_F32) by_t(float{}); else if (itype == VIVIM_F16) by_t(f16_t{}); else by_t(bf16_t{});
     if (e != hipSuccess || nb <= 0) { (void)hipGetLastError(); nb = 2; }
