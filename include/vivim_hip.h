@@ -263,7 +263,8 @@ size_t vivim_scan_fwd_workspace_bytes(const vivim_ssm_fwd_params *f);
 
 /* Kernel-selection override for tuning and tests: which = 0 forward scan (0 automatic, 1 n-split K=8, 2 n-split K=4,
  * 3 generic, 5 lanes=channels, 6 lanes=states), which = 1 backward scan (0 automatic, 1 / 2 lanes=tokens kernel with
- * 8 / 4 waves per workgroup, 3 generic, 4 lanes=states).  Forward values 1-3 also select the long checkpoint rows
+ * 8 / 4 waves per workgroup, 3 generic, 4 lanes=states first generation, 5 lanes=states second generation = what
+ * automatic takes for dstate 16 on 16-byte aligned rows).  Forward values 1-3 also select the long checkpoint rows
  * (vivim_scan_ckpt_len), which the lanes=states backward cannot use.  Returns the previous value, -1 on a bad argument.  Initial values come from VIVIM_FWD_VARIANT / VIVIM_BWD_VARIANT.  The forward workspace size depends on
  * the forward setting: query it after changing it. */
 int vivim_set_tuning(int which, int value);

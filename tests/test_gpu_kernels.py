@@ -371,7 +371,7 @@ def test_scan_optional_arguments(has_z, has_D, has_bias, softplus, cuda, ops):
 # Every forward / backward kernel family must agree with the oracle, not only the one the dispatcher prefers:
 # vivim_set_tuning (include/vivim_hip.h) pins the family for the duration of a test.
 FWD_VARIANTS = {"auto": 0, "nsplit_k8": 1, "nsplit_k4": 2, "generic": 3, "channels": 5, "states": 6}
-BWD_VARIANTS = {"auto": 0, "fast_w8": 1, "fast_w4": 2, "generic": 3, "states": 4}
+BWD_VARIANTS = {"auto": 0, "fast_w8": 1, "fast_w4": 2, "generic": 3, "states": 4, "states2": 5}
 
 
 @pytest.fixture
@@ -416,6 +416,23 @@ def test_scan_kernel_families_dstate64(fwd, bwd, dtype, batch, dim, L, G, cuda, 
     tuning(FWD_VARIANTS[fwd], BWD_VARIANTS[bwd])
     gen = torch.Generator().manual_seed(dim + L)
     _check_scan(_rand_scan(gen, batch, dim, 64, L, G, dtype, cuda, init="module"), ss)
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(has_z=False), dict(has_D=False, has_bias=False), dict(softplus=False)])
+@pytest.mark.parametrize("dtype,batch,dim,L,G,strided", [(torch.bfloat16, 3, 128, 20480, 1, True), (torch.float32, 2, 96, 5124, 3, False),
+                                                        (torch.float16, 1, 80, 1288, 1, False)])
+def test_scan_second_generation_states_backward(opts, dtype, batch, dim, L, G, strided, cuda, ops, tuning):
+    """scan_ls2.hip pinned (backward 5) behind the forward that writes 16-token checkpoints for every row length: long
+    (L, B*L, 1)-strided rows cut into many segments at multiples of 256 tokens (lanes=tokens pre-pass + carry in front of the
+    lanes=states main kernel), a row length that is not a multiple of a span or a tile, ragged channel blocks (96 = 64 + 32
+    channels, three groups; 80 = 64 + 16), and every optional input off in turn (no z: the other instantiation)."""
+    ss, _ = ops
+    tuning(FWD_VARIANTS["channels"], BWD_VARIANTS["states2"])
+    gen = torch.Generator().manual_seed(dim + L)
+    # without softplus delta itself is the step size: the module initialisation has negative ones (states grow without bound
+    # over 20480 tokens, in the oracle too), the reference tests' distribution (0.5 * U(0, 1), test_selective_scan.py:87) has not
+    init = "module" if opts.get("softplus", True) else "test"
+    _check_scan(_rand_scan(gen, batch, dim, 16, L, G, dtype, cuda, strided=strided, init=init, **opts), ss)
 
 
 @pytest.mark.parametrize("fwd", ["nsplit_k8", "channels", "states"])

@@ -864,7 +864,7 @@ static BwdPlan bwd_plan(const vivim_ssm_fwd_params& f) {
 }
 
 // The lanes = states family (scan_ls.hip) takes every shape whose checkpoints were written for it (scan_ckpt_len), unless
-// the tuning selector pins one of the kernels of this file (1 / 2: fast kernel with 8 / 4 waves, 3: generic; 4 pins it).
+// the tuning selector pins one of the kernels of this file (1 / 2: fast kernel with 8 / 4 waves, 3: generic; 4 pins its first-generation main kernel, 5 the second-generation one of scan_ls2.hip).
 static bool bwd_takes_ls(const vivim_ssm_fwd_params& f) {
     const int tv = tuning_bwd_variant();
     return ls_shape_ok(f) && scan_ckpt_len(f) == ls_ckpt_len(f) && (tv == 0 || tv == 4 || tv == 5);
@@ -933,6 +933,39 @@ static void launch_bwd_fast(const vivim_ssm_bwd_params& p, const BwdPlan& plan, 
     };
     if (f.z) { if (da_lds) launch(ssm_bwd_fast_kernel<T, K, true, W, true>); else launch(ssm_bwd_fast_kernel<T, K, true, W, false>); }
     else     { if (da_lds) launch(ssm_bwd_fast_kernel<T, K, false, W, true>); else launch(ssm_bwd_fast_kernel<T, K, false, W, false>); }
+}
+
+// The lanes = tokens pre-pass + carry on somebody else's cut of the token axis: S segments of seg_tokens tokens each, a
+// multiple of 256 (scan_ls.hip uses it for the lanes = states main kernels on long rows: the closed-form pre-pass of this
+// file runs at half the time of the recurrence form there -- cfg 3 grouped stage 0: 989 against 1931 us).  Same workspace
+// layout and the same meaning of agg / dsum / gin.  The caller has checked 16-byte aligned rows of delta, dout, z and C.
+template <typename T, int K>
+static void launch_prepass_only(const vivim_ssm_bwd_params& p, const BwdSeg& sg, hipStream_t stream) {
+    const vivim_ssm_fwd_params& f = p.f;
+    const int cpg = f.dim / f.n_groups;
+    const int ppg = (cpg + kBwR - 1) / kBwR;
+    const size_t per_wave = (size_t)f.dstate * kBwR * kWave * sizeof(float);
+    int nw = (int)((size_t)65536 / per_wave);
+    nw = nw > kPreW ? kPreW : (nw < 1 ? 1 : nw);
+    dim3 gpre(((ppg + nw - 1) / nw) * f.n_groups, f.batch, sg.S - 1);
+    if (f.z) hipLaunchKernelGGL((ssm_bwd_prepass_kernel<T, K, true, 16>), gpre, dim3(nw * kWave), nw * per_wave, stream, p, sg);
+    else     hipLaunchKernelGGL((ssm_bwd_prepass_kernel<T, K, false, 16>), gpre, dim3(nw * kWave), nw * per_wave, stream, p, sg);
+    const int64_t nthr = (int64_t)f.batch * f.dim * f.dstate;
+    hipLaunchKernelGGL(ssm_bwd_carry_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream, p, sg);
+}
+bool fast_bwd_prepass(const vivim_ssm_bwd_params& p, int S, int seg_tokens, float* agg, float* gin, float* dsum, hipStream_t stream) {
+    const vivim_ssm_fwd_params& f = p.f;
+    if (S <= 1 || f.dstate != 16 || seg_tokens % 256 != 0) return false;
+    const bool k8 = seg_tokens % 512 == 0 && f.seqlen % 8 == 0;
+    if (!k8 && f.seqlen % 4 != 0) return false;
+    const BwdSeg sg = {S, seg_tokens / (k8 ? 512 : 256), agg, dsum, gin};
+    switch (f.itype) {
+        case VIVIM_F32: if (k8) launch_prepass_only<float, 8>(p, sg, stream); else launch_prepass_only<float, 4>(p, sg, stream); break;
+        case VIVIM_F16: if (k8) launch_prepass_only<f16_t, 8>(p, sg, stream); else launch_prepass_only<f16_t, 4>(p, sg, stream); break;
+        case VIVIM_BF16: if (k8) launch_prepass_only<bf16_t, 8>(p, sg, stream); else launch_prepass_only<bf16_t, 4>(p, sg, stream); break;
+        default: return false;
+    }
+    return true;
 }
 
 template <typename T, int K>

@@ -765,6 +765,7 @@ static int ls_bwd_blocks_per_cu(const vivim_ssm_fwd_params& f, int W) {
 
 // second-generation main kernel (scan_ls2.hip): same workgroup geometry, its own residency
 bool ls2_bwd_ok(const vivim_ssm_bwd_params& p);
+bool fast_bwd_prepass(const vivim_ssm_bwd_params& p, int S, int seg_tokens, float* agg, float* gin, float* dsum, hipStream_t stream);   // scan_bwd.hip
 void ls2_bwd_launch(const vivim_ssm_bwd_params& p, const LsSeg& sg, int W, hipStream_t stream);
 int ls2_bwd_blocks_per_cu(int itype, bool has_z, int W);
 // Which main kernel a shape gets is decided from sizes alone (the workspace query has no pointers): dstate 16 and the
@@ -791,6 +792,13 @@ static void ls_bwd_plan(const vivim_ssm_fwd_params& f, int& W, int& S, int& seg_
         nb = ls_bwd_blocks_per_cu(f, W);
     }
     ls_segmentation(f, waves_per_seg, ls_cu_count() * nb * W, 4, S, seg_blocks);
+    // Long segments are cut at multiples of 256 tokens, so that the lanes = tokens pre-pass (scan_bwd.hip: fast_bwd_prepass,
+    // closed form, 16-byte vector loads) can stand in for the recurrence form of this file.
+    if (ls2_wanted(f) && S > 1 && seg_blocks >= 12) {
+        const int nck = (f.seqlen + 15) / 16;
+        seg_blocks = (seg_blocks + 8) / 16 * 16;
+        S = (nck + seg_blocks - 1) / seg_blocks;
+    }
 }
 // the forward / pre-pass kernels: 7 - 8 waves per SIMD (<= 72 VGPRs), no LDS
 static void ls_fwd_plan(const vivim_ssm_fwd_params& f, int& S, int& seg_blocks) {
@@ -845,7 +853,11 @@ static bool launch_ls_bwd(const vivim_ssm_bwd_params& p, hipStream_t stream) {
     }
     const int cpg = f.dim / f.n_groups;
     const int bpg = (cpg + W * G::CPW - 1) / (W * G::CPW);
-    if (sg.S > 1) {
+    const bool second_gen = NS == 16 && ls2_wanted(f) && ls2_bwd_ok(p);
+    if (sg.S > 1 && second_gen && (sg.seg_blocks * 16) % 256 == 0 &&
+        fast_bwd_prepass(p, sg.S, sg.seg_blocks * 16, sg.agg, sg.gin, sg.dsum, stream)) {
+        // pre-pass + carry done by the lanes = tokens kernels
+    } else if (sg.S > 1) {
         const int PW = 4;                                     // independent waves per pre-pass workgroup, one channel per row
         const int pbpg = (cpg + PW * G::SPW - 1) / (PW * G::SPW);
         const dim3 gpre(pbpg * f.n_groups, f.batch, sg.S - 1);
@@ -855,7 +867,7 @@ static bool launch_ls_bwd(const vivim_ssm_bwd_params& p, hipStream_t stream) {
         hipLaunchKernelGGL((ssm_ls_carry_kernel<true>), dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
                            static_cast<const float*>(f.A), f.A_d_stride, f.A_dstate_stride, f.batch, f.dim, f.dstate, sg);
     }
-    if (NS == 16 && ls2_wanted(f) && ls2_bwd_ok(p)) {
+    if (second_gen) {
         ls2_bwd_launch(p, sg, W, stream);
         return true;
     }
