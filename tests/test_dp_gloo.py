@@ -76,6 +76,59 @@ def test_ddp_gloo_world2(tmp_path):
     assert torch.allclose(r0["grads"], want, atol=1e-6)                    # = gradient of the global batch
 
 
+def _mamba_worker(rank, world, port, out):
+    """The REAL v3 Mamba module (three directions' parameters = views of fused (3, ...) storage) inside a 2-rank gloo DDP.
+    No kernel runs (there is no GPU here and the product has no CPU path): the loss is a rank-dependent linear form of
+    the parameters, which is all DDP's reducer, its buckets and the parameter broadcast ever see."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from vivim_amd import dp
+    from vivim_amd.mamba_simple import Mamba
+    dp.init(backend="gloo")
+    torch.manual_seed(11 + rank)                           # DIFFERENT initial replicas: DDP's broadcast must repair them
+    m = Mamba(d_model=32, d_state=16, bimamba_type="v3", nframes=3)
+    m._fuse()
+    ptr = {n: p.data_ptr() for n, p in m.named_parameters()}
+    ddp = dp.wrap(m)
+    # (ii) the views survive DDP's construction (parameter broadcast from rank 0, bucket views)
+    assert {n: p.data_ptr() for n, p in m.named_parameters()} == ptr
+    for k, buf in enumerate(m._fused):
+        if buf is not None:
+            assert buf[0].data_ptr() == [m.conv1d.weight, m.conv1d.bias, m.x_proj.weight, m.dt_proj.weight, m.dt_proj.bias,
+                                         m.A_log, m.D][k].data_ptr()
+    w0 = torch.cat([p.detach().flatten() for p in m.parameters()])
+    fused0 = torch.cat([b.flatten() for b in m._fused if b is not None])
+
+    class Lin(torch.nn.Module):                            # forward through DDP: loss = sum_p <p, c_rank>
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+
+        def forward(self, scale):
+            return sum((p * (scale * (i % 5 + 1))).sum() for i, p in enumerate(self.inner.parameters()))
+    ddp = dp.wrap(Lin(m))
+    ddp(float(rank + 1)).backward()
+    assert {n: p.data_ptr() for n, p in m.named_parameters()} == ptr      # gradient_as_bucket_view moved no parameter
+    grads = {n: p.grad.clone() for n, p in m.named_parameters()}
+    assert all(g is not None for g in grads.values())                     # (i) every Parameter view got a gradient
+    torch.save({"w0": w0, "fused0": fused0, "grads": grads}, os.path.join(out, f"m{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+def test_real_mamba_fused_views_in_ddp_world2(tmp_path):
+    """multi-rank readiness of the fused parameter storage without a node."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_mamba_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"m{i}.pt") for i in range(2))
+    assert torch.equal(r0["w0"], r1["w0"]) and torch.equal(r0["fused0"], r1["fused0"])    # broadcast reached the fused buffers
+    for i, (n, g) in enumerate(r0["grads"].items()):
+        assert torch.equal(g, r1["grads"][n])
+        assert torch.allclose(g, torch.full_like(g, 1.5 * (i % 5 + 1))), n             # (iii) the two-rank mean of (1, 2) * c
+
+
 def test_single_process_helpers_are_identity():
     sys.path.insert(0, ROOT)
     from vivim_amd import dp

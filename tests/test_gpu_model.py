@@ -154,6 +154,17 @@ def test_fused_parameter_storage(cuda, monkeypatch):
     y5, _ = run()
     assert m._fused[2].data_ptr() == m.x_proj.weight.data_ptr()
     assert rel_err(y5, y3) < 2e-3                           # the fp16 round trip of the weights
+    # ONE middle Parameter gets new storage / is re-assigned: every fused Parameter is re-checked per call
+    m.A_b_log.data = m.A_b_log.data.clone() + 0.3
+    m.dt_proj_b.bias = torch.nn.Parameter(m.dt_proj_b.bias.detach().clone() - 0.5)
+    assert m._fused[5][1].data_ptr() != m.A_b_log.data_ptr()
+    y6, g6 = run()
+    assert m._fused[5][1].data_ptr() == m.A_b_log.data_ptr() and m._fused[4][1].data_ptr() == m.dt_proj_b.bias.data_ptr()
+    monkeypatch.setenv("VIVIM_SEPARATE_DIRECTIONS", "1")
+    y7, g7 = run()
+    monkeypatch.delenv("VIVIM_SEPARATE_DIRECTIONS")
+    assert rel_err(y6, y7) < 2e-5 and rel_err(y6, y5) > 1e-3
+    assert rel_err(g6["dt_proj_b.bias"], g7["dt_proj_b.bias"]) < 2e-4
 
 
 def test_module_nframes_override_and_autocast(cuda):

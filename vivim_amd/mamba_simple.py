@@ -123,19 +123,38 @@ class Mamba(nn.Module):
         self._fused = bufs
         self._fused_live = [b for b in bufs if b is not None]
         self._fused_args = self._fused_live + [p for ps in groups if ps is not None for p in ps]
-        self._fused_check = (groups[2][0], groups[6][2])     # first and last Parameter fused: x_proj.weight, D_s
+        # (owner module, attribute, buffer, row) of every fused Parameter: what _fused_params re-checks on each call
+        self._fused_where = []
+        for kind, buf in zip(_FUSED, bufs):
+            if buf is None:
+                continue
+            for g, sfx in enumerate(_DIRECTIONS):
+                *mods, attr = kind.format(sfx).split(".")
+                owner = self
+                for name in mods:
+                    owner = getattr(owner, name)
+                self._fused_where.append((owner, attr, buf, g))
 
     def _fused_params(self):
         """-> [conv_w (3, D, 1, W), conv_b (3, D) | None, x_proj_w (3, R + 2N, D), dt_proj_w (3, D, R), dt_bias (3, D),
-        A_log (3, D, N), D (3, D)] with autograd edges to the per-direction Parameters."""
-        bufs = getattr(self, "_fused", None)
-        if bufs is not None:
-            first, last = self._fused_check
-            ok = (bufs[2].data_ptr() == first.data_ptr() and bufs[6][2].data_ptr() == last.data_ptr()
-                  and bufs[2].dtype == first.dtype and first is self.x_proj.weight)
-        if bufs is None or not ok:
+        A_log (3, D, N), D (3, D)] with autograd edges to the per-direction Parameters.
+        EVERY fused Parameter is looked up again and compared with its row of the buffer (21 attribute reads and data_ptr()
+        calls per forward): a Parameter that was re-assigned, or whose .data got new storage (`m.A_b_log.data = t`, a partial
+        load_state_dict(assign=True), a `.to()`), makes the module fuse again instead of training on a buffer that
+        state_dict() no longer reports."""
+        where = getattr(self, "_fused_where", None)
+        ok = where is not None
+        if ok:
+            args = self._fused_args
+            k = len(self._fused_live)
+            for i, (owner, attr, buf, g) in enumerate(where):
+                prm = getattr(owner, attr)
+                if prm is not args[k + i] or prm.data_ptr() != buf[g].data_ptr() or prm.dtype != buf.dtype or prm.device != buf.device:
+                    ok = False
+                    break
+        if not ok:
             self._fuse()
-            bufs = self._fused
+        bufs = self._fused
         views = iter(_FusedViews.apply(len(self._fused_live), *self._fused_args))
         return [None if b is None else next(views) for b in bufs]
 
