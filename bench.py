@@ -158,6 +158,52 @@ def pmc_record(entry_point):
 
 VALU_PEAK_GINST = 1024 * 2.4 / 2      # G wave-instructions per s: 1024 SIMD-32 x 2.4 GHz, one wave64 instruction per 2 cycles
 
+# The scans' OTHER roof, spelled out.  A state update (one token, one channel, one state) needs at
+# least these vector instructions; a wave64 instruction does 64 of them.  Issue time per instruction class, measured on
+# MI355X at >= 2 waves per SIMD (profiles/r02_valu_lab2.log, r02_valu_lab3.log; tools/valu_lab_gen.py): plain fp32
+# fma / mul / add on VGPRs 1.3 ns per wave-instruction and SIMD, v_exp_f32 3.5 ns, DPP / cross-lane forms 1.9 ns.
+VALU_NS = {"plain": 1.3, "exp": 3.5, "dpp": 1.9}
+VALU_IDEAL = {   # instruction classes per state update
+    # h = exp2(delta A) h + (delta u) B; y += h C: mul, exp, mul, fma, fma
+    "selective_scan_fwd": {"plain": 4, "exp": 1, "dpp": 0},
+    # + the segment pre-pass when the token axis is cut for parallelism (every shape here): mul, exp, mul, fma
+    "selective_scan_fwd_split": {"plain": 7, "exp": 2, "dpp": 0},
+    # forward states again (mul, exp, mul, fma) + g, a g, x = a g h, g B, A x, dA, dB, dC (8) + the two sums over the states,
+    # which no mapping gets without cross-lane work (>= 4 DPP-class instructions per update in ours: DESIGN.md 4.10)
+    "selective_scan_bwd": {"plain": 11, "exp": 1, "dpp": 4},
+    # + the closed-form pre-pass of the token-axis cut: mul, exp, fma
+    "selective_scan_bwd_split": {"plain": 13, "exp": 2, "dpp": 4},
+}
+N_SIMD = 1024
+
+
+def valu_ceiling(kernel, state_updates, alg_bytes):
+    """-> dict: the least VALU issue time of one launch (all 1024 SIMDs busy, nothing but the instructions above) and the
+    algorithmic GB/s that time allows, capped by the HBM peak."""
+    mix = VALU_IDEAL[kernel + "_split"]
+    ns_per_wave_update = sum(mix[c] * VALU_NS[c] for c in mix)
+    t = state_updates / 64.0 / N_SIMD * ns_per_wave_update * 1e-9
+    return {"instr_per_update": mix, "ns_per_wave_update": round(ns_per_wave_update, 2), "ideal_valu_us": round(t * 1e6, 1),
+            "ceiling_GBps": round(min(HBM_PEAK_GBS, alg_bytes / t / 1e9), 1)}
+
+
+def kbench_traffic():
+    """-> {cfg: {entry point: record}} from the newest committed profiles/r*_kbench_pmc_traffic.json (tools/pmc_kbench.sh), or
+    {} when none is committed or it was taken on other kernel sources."""
+    import glob
+    import re
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kbench_pmc_traffic.json")),
+                   key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
+    if not files:
+        return {}, None, False
+    try:
+        from pmc_bench_traffic import kernels_sha
+        doc = json.load(open(files[-1]))
+        return doc["per_config"], os.path.relpath(files[-1], ROOT), doc.get("kernels_sha") != kernels_sha()
+    except (KeyError, ValueError, OSError, ImportError):
+        return {}, None, False
+
 
 def roofline_by_config(dev, iters=4):
     """The scan kernels alone at the stage-0 shapes of BASELINE.json configs[1], [2] and [4] (the grouped v3 layout: three
@@ -167,6 +213,7 @@ def roofline_by_config(dev, iters=4):
     import selective_scan_cuda as ss
     from vivim_amd import _lib
     out = {}
+    traffic, traffic_src, traffic_stale = kbench_traffic()
     for key, (B, nf, img, N, expand, dt) in {"cfg2": (3, 5, 256, 16, 2, torch.bfloat16), "cfg3": (8, 5, 512, 16, 2, torch.float32),
                                              "cfg5": (1, 8, 256, 64, 4, torch.bfloat16)}.items():
         G, D, L = 3, 64 * expand * 3, nf * (img // 4) ** 2
@@ -190,9 +237,19 @@ def roofline_by_config(dev, iters=4):
         for name in ("vivim_selective_scan_fwd", "vivim_selective_scan_bwd"):
             rows = [x for x in rec if x[0] == name]
             sec, nb = sum(x[2] for x in rows), sum(x[1] for x in rows)
-            e[name.replace("vivim_", "")] = {"avg_us": round(sec / len(rows) * 1e6, 1), "achieved_GBps": round(nb / sec / 1e9, 1),
-                                             "frac": round(nb / sec / 1e9 / HBM_PEAK_GBS, 4),
-                                             "state_updates_per_launch": B * D * L * N}
+            short = name.replace("vivim_", "")
+            ceil = valu_ceiling(short, B * D * L * N, nb / len(rows))
+            tr = traffic.get(key, {}).get(short, {})
+            e[short] = {"avg_us": round(sec / len(rows) * 1e6, 1), "achieved_GBps": round(nb / sec / 1e9, 1),
+                        "frac": round(nb / sec / 1e9 / HBM_PEAK_GBS, 4),
+                        "state_updates_per_launch": B * D * L * N,
+                        "algorithmic_bytes_per_launch": int(nb / len(rows)),
+                        # the lower of the two roofs for THIS shape, and how far the launch is from it
+                        "ceiling_GBps": ceil["ceiling_GBps"], "frac_of_ceiling": round(nb / sec / 1e9 / ceil["ceiling_GBps"], 4),
+                        "valu_ideal": ceil,
+                        "traffic": None if traffic_stale else tr.get("hbm_bytes_per_launch"),
+                        "traffic_source": traffic_src, "traffic_stale": bool(traffic_stale),
+                        "valu_wave_insts_per_launch": None if traffic_stale else tr.get("valu_wave_insts_per_launch")}
         out[key] = e
         del u, z, dout, delta, Bm, Cm, res, dz, r
         torch.cuda.empty_cache()

@@ -77,7 +77,11 @@ typedef struct {
     const void *D;              /* (dim) f32 or NULL */
     const void *delta_bias;     /* (dim) f32 or NULL */
     const void *z;              /* (batch, dim, seqlen) itype or NULL */
-    void *out;                  /* (batch, dim, seqlen) itype: y + D*u, before gating */
+    void *out;                  /* (batch, dim, seqlen) itype: y + D*u, before gating.  The reference allocates out / out_z with
+                                   delta's / z's strides (selective_scan.cpp:311-313); a shape that gets the short checkpoint
+                                   rows (vivim_scan_ckpt_len() == 16 * (dstate / 16)) needs every (channel, token) byte offset
+                                   of out / out_z inside one batch element below 2^32 - 2^16, as it already holds for delta / z
+                                   there: other strides return VIVIM_ERR_UNSUPPORTED */
     void *out_z;                /* out * silu(z); required iff z != NULL */
     void *x;                    /* (batch, dim, n_chunks, dstate) f32 contiguous: state after each chunk of
                                    vivim_scan_ckpt_len() tokens; x[:, :, -1, :] is the final state

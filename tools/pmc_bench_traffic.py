@@ -9,11 +9,11 @@ import csv, glob, hashlib, json, os, sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-GROUPS = {"selective_scan_bwd": ("ssm_bwd", "ssm_ls_bwd", "ssm_ls_carry_kernelILb1", "ssm_ls_carry_kernel<true>"),
+GROUPS = {"selective_scan_bwd": ("ssm_bwd", "ssm_ls_bwd", "ssm_ls2_bwd", "ssm_ls_carry_kernelILb1", "ssm_ls_carry_kernel<true>"),
           "selective_scan_fwd": ("ssm_fwd", "ssm_ls_fwd", "ssm_ls_carry_kernelILb0", "ssm_ls_carry_kernel<false>"),
           "causal_conv1d_fwd": ("conv1d_fwd",), "causal_conv1d_bwd": ("conv1d_bwd",)}
 # one dispatch of these per entry-point call
-MAIN = {"selective_scan_bwd": ("ssm_ls_bwd_kernel", "ssm_bwd_fast_kernel", "ssm_bwd_generic_kernel"),
+MAIN = {"selective_scan_bwd": ("ssm_ls_bwd_kernel", "ssm_ls2_bwd_kernel", "ssm_bwd_fast_kernel", "ssm_bwd_generic_kernel"),
         "selective_scan_fwd": ("ssm_fwd_nsplit_kernel", "ssm_fwd_generic_kernel",
                                "ssm_fwd_bc_kernel",            # lanes=channels: once per call (its two passes share a name)
                                "ELi2ELb", ", 2, true>", ", 2, false>"),       # lanes=states: PASS == 2
@@ -41,7 +41,35 @@ def total(d, counter):
     return out, main
 
 
-if __name__ == "__main__":
+def record(fetch_dir, write_dir, valu_dir):
+    (fetch, nf) = total(fetch_dir, "FETCH_SIZE")
+    (wr, nw), (wr64, _) = total(write_dir, "TCC_EA0_WRREQ_sum"), total(write_dir, "TCC_EA0_WRREQ_64B_sum")
+    write = {g: ((wr[g] - wr64.get(g, 0.0)) * 32 + wr64.get(g, 0.0) * 64) / 1024 for g in wr}
+    valu, nv = total(valu_dir, "SQ_INSTS_VALU") if valu_dir != "-" else ({}, {})
+    res = {}
+    for g in GROUPS:
+        if not nf.get(g) or not nw.get(g):
+            continue
+        res[g] = {"launches_profiled": nf[g], "fetch_KiB_per_launch": round(fetch[g] / nf[g], 1),
+                  "write_KiB_per_launch": round(write[g] / nw[g], 1),
+                  "hbm_bytes_per_launch": int((2 * fetch[g] / nf[g] + write[g] / nw[g]) * 1024)}
+        if nv.get(g):
+            res[g]["valu_wave_insts_per_launch"] = int(valu[g] / nv[g])
+    return res
+
+
+if __name__ == "__main__" and sys.argv[1] == "--kbench":
+    # python tools/pmc_bench_traffic.py --kbench <scratch dir with cfgN_{fetch,write,valu} pass directories> <out.json>
+    doc = {"note": "rocprofv3 --pmc passes (one counter set per pass) over `tools/kbench.py --config N --groups 3 --stages 0 --kernels "
+                   "sf,sb`: the grouped stage-0 scans of BASELINE configs 2 / 3 / 5; reads doubled (gfx950)",
+           "kernels_sha": kernels_sha(), "per_config": {}}
+    for cfg in ("cfg2", "cfg3", "cfg5"):
+        d = os.path.join(sys.argv[2], cfg)
+        if os.path.isdir(d + "_fetch"):
+            doc["per_config"][cfg] = record(d + "_fetch", d + "_write", d + "_valu" if os.path.isdir(d + "_valu") else "-")
+    json.dump(doc, open(sys.argv[3], "w"), indent=1)
+    print(json.dumps(doc["per_config"], indent=1))
+elif __name__ == "__main__":
     (fetch, nf) = total(sys.argv[1], "FETCH_SIZE")
     (write, nw) = total(sys.argv[2], "WRITE_SIZE")
     if not nw:                                       # raw request counters instead of the derived metric (KiB like WRITE_SIZE)

@@ -686,7 +686,9 @@ bool ls_shape_ok(const vivim_ssm_fwd_params& f) {
     if (!(f.is_variable_B && f.is_variable_C && (f.dstate == 16 || f.dstate == 32 || f.dstate == 64) && f.dim % f.n_groups == 0))
         return false;
     const int es = f.itype == VIVIM_F32 ? 4 : 2;
-    if (f.dim > 65535 || !ls_span_ok(f.dim, f.u_d_stride, f.seqlen, es) || !ls_span_ok(f.dim, f.delta_d_stride, f.seqlen, es) ||
+    // (the resource's size field carries the channel, 0xffff0000 + chu, and a lane that is off stores at offset 0xfffffff0,
+    // which must stay >= that size: chu < 65520)
+    if (f.dim > 65520 || !ls_span_ok(f.dim, f.u_d_stride, f.seqlen, es) || !ls_span_ok(f.dim, f.delta_d_stride, f.seqlen, es) ||
         !ls_span_ok(f.dstate, f.B_dstate_stride, f.seqlen, es) || !ls_span_ok(f.dstate, f.C_dstate_stride, f.seqlen, es) ||
         !ls_span_ok(f.dim, (int64_t)((f.seqlen + 15) / 16) * f.dstate, 0, 4))
         return false;
@@ -700,6 +702,9 @@ static int ls_bwd_waves(const vivim_ssm_fwd_params& f) {
     const int cpw = (4 / (f.dstate / 16)) * kLsCPR;
     const int cpg = f.dim / f.n_groups;
     int w = (cpg + cpw - 1) / cpw;
+    // (8 waves = one workgroup per 128-channel group, plain dB / dC stores instead of two atomic contributions, measured
+    // SLOWER with the second-generation kernel: 583 against 557 us at cfg 2 grouped stage 0, 6466 against 5481 at cfg 3 --
+    // one workgroup per CU has nobody to run while it waits at its barriers)
     return w > 4 ? 4 : w;
 }
 
@@ -723,7 +728,7 @@ static void ls_segmentation(const vivim_ssm_fwd_params& f, int waves_per_seg, in
 // Resident workgroups per CU of the backward instantiation that `f` selects, from the occupancy query (registers and LDS
 // differ between instantiations: 2 or 3 waves per SIMD); cached.  A build host without a GPU answers 3.
 template <typename T, int NS, bool HAS_Z> static int ls_bwd_blocks_per_cu_of(int W, size_t smem) {
-    static int cache[5] = {0, 0, 0, 0, 0};                    // by W (1..4)
+    static int cache[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};        // by W (1..8)
     if (cache[W] == 0) {
         int nb = 0;
         if (smem > 65536)
@@ -782,7 +787,7 @@ static void ls_bwd_plan(const vivim_ssm_fwd_params& f, int& W, int& S, int& seg_
     const int cpg = f.dim / f.n_groups;
     const int bpg = (cpg + W * cpw - 1) / (W * cpw);
     const int waves_per_seg = bpg * W * f.n_groups * f.batch;
-    static int nb2[3][2][5] = {};
+    static int nb2[3][2][9] = {};
     int nb;
     if (ls2_wanted(f)) {
         int& c = nb2[f.itype][f.z != nullptr][W];
