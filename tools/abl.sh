@@ -36,6 +36,11 @@ if [ "$mode" = chanrun ]; then
   done
   exit 0
 fi
+if [ "$mode" = dirbuild ]; then      # direction maps without the identity / flip copies (-DDIR_ABL=1)
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -DDIR_ABL=1 -c dirmap.hip -o abl/dirmap_1.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o abl/libvivim_dirabl_1.so capi.o conv1d.o conv1d_cl.o scan_fwd.o scan_fwd_chan.o scan_ls.o scan_ls2.o scan_bwd.o dwconv.o abl/dirmap_1.o update.o
+  echo "built dir abl 1"; exit 0
+fi
 if [ "$mode" = ls2build ]; then      # second-generation lanes=states backward (-DLS2_ABL=n)
   for n in "$@"; do
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -DLS2_ABL=$n -Rpass-analysis=kernel-resource-usage -c scan_ls2.hip -o abl/scan_ls2_$n.o 2> abl/scan_ls2_$n.res

@@ -64,6 +64,12 @@ __global__ void __launch_bounds__(256) dir_kernel(const vivim_dir_params p) {
 // side -- so direction 2 is written (read) with whole 16-byte vectors too.  The element-wise kernel above issued E two-byte
 // stores per thread into lines that four other workgroups complete (30.8 us per launch in the bench, 16 launches per
 // step: half the time of all forward scans).  Needs hw % E == 0 (vectors of a frame's piece stay aligned) and nf <= 16.
+// DIR_ABL (tools/abl.sh dirbuild; timing only, results WRONG): 1 = directions 0 and 1 are neither written (scatter) nor read
+// (gather) -- what the two maps would cost if the conv / scan kernels read xz themselves, forward and reversed (SURVEY.md
+// 8f row 1), and only the frame interleave stayed a copy.
+#ifndef DIR_ABL
+#define DIR_ABL 0
+#endif
 constexpr int kDirMaxFrames = 16;
 template <typename T, bool GATHER>
 __global__ void __launch_bounds__(256) dir_tile_kernel(const vivim_dir_params p) {
@@ -98,9 +104,12 @@ __global__ void __launch_bounds__(256) dir_tile_kernel(const vivim_dir_params p)
             const int t = i / vpf, v = i - t * vpf;
             const int l0 = t * hw + q0 + v * E;
             U a0, a1, a2, r;
-            a0.v = *reinterpret_cast<const vec*>(s + l0);
-            a1.v = *reinterpret_cast<const vec*>(s + p.stk_dir_stride + (L - E - l0));
             a2.v = *reinterpret_cast<const vec*>(lds + t * Q + v * E);
+            if (DIR_ABL == 1) { a0.v = a2.v; a1.v = a2.v; }
+            else {
+                a0.v = *reinterpret_cast<const vec*>(s + l0);
+                a1.v = *reinterpret_cast<const vec*>(s + p.stk_dir_stride + (L - E - l0));
+            }
 #pragma unroll
             for (int e = 0; e < E; ++e)
                 r.e[e] = from_f32<T>((to_f32<T>(a0.e[e]) + to_f32<T>(a1.e[E - 1 - e]) + to_f32<T>(a2.e[e])) * scale);
@@ -120,8 +129,10 @@ __global__ void __launch_bounds__(256) dir_tile_kernel(const vivim_dir_params p)
                 o0.e[e] = x;
                 o1.e[E - 1 - e] = x;
             }
-            *reinterpret_cast<vec*>(d + l0) = o0.v;
-            *reinterpret_cast<vec*>(d + p.stk_dir_stride + (L - E - l0)) = o1.v;
+            if (DIR_ABL != 1) {
+                *reinterpret_cast<vec*>(d + l0) = o0.v;
+                *reinterpret_cast<vec*>(d + p.stk_dir_stride + (L - E - l0)) = o1.v;
+            }
             *reinterpret_cast<vec*>(lds + t * Q + v * E) = o0.v;
         }
         __syncthreads();
