@@ -2,24 +2,40 @@
 //
 // Same math and same lane mapping as ssm_ls_bwd_kernel (scan_ls.hip; reference: selective_scan_bwd_kernel.cuh:146-489):
 // a 16-lane row is one channel, the lane is the state, a tile is 16 tokens, a row walks kLsCPR channels per tile and keeps
-// their dB / dC sum in registers.  What changed is everything AROUND the two sweeps, following what round 2 measured
-// (VERDICT round 2 item 1):
+// their dB / dC sum in registers; token-axis segments get their inflow from a pre-pass + carry.  What changed is everything
+// AROUND the two sweeps, following what round 2 measured and what this round's stamps said:
 //   * activations move in SPANS of one 128-byte line per channel row (64 16-bit / 32 fp32 tokens) and 16 channels per wave:
-//     u, delta, dout, z, out are read with 16-byte vectors, whole lines at a time, once per span; du / ddelta are collected
-//     in LDS in the bytes of the u / delta tokens they were computed from and leave as whole lines too; dz -- which does
-//     not depend on the scan -- is computed and stored at span level, where a lane holds eight consecutive tokens.
+//     u, delta, dout, z, out are read with 16-byte vectors, whole lines, once per span; du / ddelta leave the same way.
 //     The first-generation kernel asked for ONE element per lane and tensor in every (tile, channel) step: 32-byte row
-//     pieces whose lines were evicted between visits (3.8 x the algorithmic traffic), ten vector-memory instructions and
-//     ~150 scalar instructions of descriptor arithmetic per step.
-//   * the per-token scalars (delta, delta * u, dy) reach the 16 lanes of a row through LDS (three ds_write_b32 by the
-//     lane that owns the token, broadcast ds_read_b128 of four tokens at a time) instead of DPP row broadcasts: a VALU
-//     instruction with a DPP operand issues at half rate and is not hidden by its neighbours (profiles/r02_valu_lab3.log),
-//     and the sweeps carried six of them per state update.
-//   * the transposed reductions are written with builtins (v_cndmask pair + one DPP add per merge): hipcc sees the DPP
-//     hazards itself, so no s_nop and free scheduling across the sweep.
-//   * dB / dC: the four rows of a wave are summed in registers (v_permlane16/32_swap merges) before they go to LDS:
-//     2 KB of slots per wave instead of 8.
-// Per wave 12.75 KB (16-bit) / 10.75 KB (fp32) of LDS: three 4-wave workgroups per CU, three waves per SIMD.
+//     pieces whose lines were evicted between visits (3.8 x the algorithmic traffic; here 1.7 x), ten vector-memory
+//     instructions and ~150 scalar instructions of descriptor arithmetic per step.
+//   * everything a token needs that does not depend on the scan runs at SPAN level, where a lane holds 8 (4) consecutive
+//     tokens of one channel and their dependency chains interleave: softplus, the z gate, dz (stored right away), dD, and at
+//     the span's end the sigmoid factor of ddelta and dbias.  A (tile, channel) step is then the forward sweep, the reverse
+//     sweep with its two transposed reductions, and four instructions of output arithmetic.
+//   * the per-token scalars (delta, delta * u, dy; f32) live in LDS in token order and reach the 16 lanes of a row as
+//     broadcast ds_read_b128 of four tokens -- no DPP operands in the sweeps (a VALU instruction with a DPP operand issues at
+//     half rate and is not hidden by its neighbours, profiles/r02_valu_lab3.log; the first generation carried six per update).
+//   * the transposed reductions are written with builtins (v_cndmask pair + one DPP add per merge; level 4 pairs lane l with
+//     l ^ 7 = row_half_mirror so that every level is an involution): hipcc sees the DPP hazards itself -- no s_nop.
+//   * what a channel carries from tile to tile (reverse carry, dA, A log2e, the next checkpoint) sits in registers that
+//     rotate through slot 0; the checkpoints of a tile are requested a tile ahead and taken out of the memory queue before
+//     that tile's dB / dC atomics go in: the step loop contains no vector-memory wait.
+//   * dB / dC: the four rows of a wave are summed in registers (v_permlane16/32_swap merges) before they go to LDS.
+// Per wave 18 KB (16-bit) / 12 KB (fp32) of LDS and 232-251 VGPRs: two 4-wave workgroups per CU, two waves per SIMD.
+//
+// Measured (MI355X, tools/kbench.py grouped shapes; profiles/r03_*): the same time as the first generation on 16-bit rows
+// (cfg 2 stages 1-3: 274 / 164 / 89 us against 274 / 174 / 84) and 16 % less on long fp32 rows; with the lanes = tokens
+// closed-form pre-pass in front (scan_ls.hip: segments cut at multiples of 256 tokens) cfg 3 grouped stage 0 takes 5480 us
+// against 5760 for the lanes = tokens family -- whose forward writes 16 x fewer checkpoints, which is why the automatic
+// dispatch keeps it for rows longer than 8192 tokens.  SQ counters (profiles/r03_pmc_sq_ls2_*): 26 VALU instructions per
+// state update (12 the recurrences, 5.6 the two reductions, the rest span level, dB / dC, bookkeeping), the vector ALU busy
+// ~80 % of the time at two waves per SIMD.  What did NOT help, each built, checked and timed (profiles/r03_ls2_experiments.log):
+// two channels of a row side by side in one step for instruction-level parallelism (+5 %), B / C rows read from the
+// staged LDS copy instead of 32 registers (+6 %), the reductions as one block behind the sweep (+1 %), 8-wave workgroups
+// with plain dB / dC stores (+5 ... +18 %), three waves per SIMD with the decays recomputed (spills: not built).  Timing
+// ablations (LS2_ABL): no LDS reads in the sweeps -11 %, no reductions -15 %, no forward rebuild -14 %, no epilogue -3 %:
+// the cost is spread over the instruction stream, which is what "VALU-bound" looks like from outside.
 #include "ls_common.cuh"
 
 namespace vivim {
