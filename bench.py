@@ -357,6 +357,9 @@ def main():
                          "avg_launch_us": round(per[dom][1] / per[dom][2] * 1e6, 2),
                          "measured_copy_GBps": measured_copy_ceiling(dev)},
             "kernels": kernels,
+            # what the step holds in HBM (caching allocator peak since process start; the lanes = states family keeps 4 bytes of
+            # scan checkpoints per token and channel from forward to backward -- ADVICE round 2: compare VIVIM_FWD_VARIANT=1)
+            "max_memory_allocated_MB": round(torch.cuda.max_memory_allocated(dev) / 1e6, 1),
             "loss": round(float(loss), 5),
         }
         if comm:

@@ -11,6 +11,8 @@ out=$root/gpurun_out
 mkdir -p "$out"
 cd "$root"
 timeout -k 10 400 python bench.py > "$out/bench_$tag.json" 2> "$out/bench_$tag.err"
+# the same step with the long (256-token) checkpoint rows everywhere: peak memory and time beside the automatic choice
+VIVIM_FWD_VARIANT=1 timeout -k 10 300 python bench.py --steps 20 --no-cpu-baseline --no-by-config > "$out/bench_${tag}_longckpt.json" 2> /dev/null || true
 {
   echo "# tools/kbench.py, MI355X, $tag (automatic kernel choice)"
   echo "== grouped v3 shapes (cfg 2, --groups 3)"; timeout -k 10 200 python tools/kbench.py --config 2 --groups 3 --iters 30 2>&1 | grep stage
