@@ -193,7 +193,7 @@ __device__ __forceinline__ void stamp(int step, int slot, int wave, int lane) {
     unsigned long long t;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    if (g_stamp_buf && lane == 0 && step < kStampSteps && blockIdx.x < 2 && blockIdx.y == 0)
+    if (g_stamp_buf && lane == 0 && step < kStampSteps && blockIdx.x < 2 && blockIdx.y == 0 && blockIdx.z == 0)
         g_stamp_buf[((blockIdx.x * kStampWaves + wave) * kStampSteps + step) * kStampSlots + slot] = t;
 }
 #define VIVIM_STAMP(step, slot, wave, lane) stamp(step, slot, wave, lane)

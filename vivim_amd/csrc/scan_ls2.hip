@@ -478,6 +478,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             // waves of the workgroup through LDS.  R[k], row r = the wave's total of vector 4 k + r (0-15 dB, 16-31 dC by token).
             if constexpr (kAbl2 == 1) continue;
             LS2_STAMP(5);
+            // (the dB / dC bases: scalar loads from the argument block, requested here so that they are in when the barriers are)
+            const ls_kargs qe = ls_fresh_kargs();
+            float* __restrict__ dBg = ls_karg<float*>(qe, LS_OFF(BP, dB)) + b * ls_karg<int64_t>(qe, LS_OFF(BP, dB_batch_stride)) + g * ls_karg<int64_t>(qe, LS_OFF(BP, dB_group_stride));
+            float* __restrict__ dCg = ls_karg<float*>(qe, LS_OFF(BP, dC)) + b * ls_karg<int64_t>(qe, LS_OFF(BP, dC_batch_stride)) + g * ls_karg<int64_t>(qe, LS_OFF(BP, dC_group_stride));
+            const int dBns = (int)ls_karg<int64_t>(qe, LS_OFF(BP, dB_dstate_stride)), dCns = (int)ls_karg<int64_t>(qe, LS_OFF(BP, dC_dstate_stride));
             float R[8];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -503,10 +508,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
             for (int c = 0; c < CPR; ++c) hcur[c] = hnxt[c];
             {
-                const ls_kargs q = ls_fresh_kargs();
-                float* __restrict__ dBg = ls_karg<float*>(q, LS_OFF(BP, dB)) + b * ls_karg<int64_t>(q, LS_OFF(BP, dB_batch_stride)) + g * ls_karg<int64_t>(q, LS_OFF(BP, dB_group_stride));
-                float* __restrict__ dCg = ls_karg<float*>(q, LS_OFF(BP, dC)) + b * ls_karg<int64_t>(q, LS_OFF(BP, dC_batch_stride)) + g * ls_karg<int64_t>(q, LS_OFF(BP, dC_group_stride));
-                const int dBns = (int)ls_karg<int64_t>(q, LS_OFF(BP, dB_dstate_stride)), dCns = (int)ls_karg<int64_t>(q, LS_OFF(BP, dC_dstate_stride));
                 auto slot_of = [&](int e) __attribute__((always_inline)) -> const float* {
                     const int isC = e >> 8, en = (e >> 4) & 15, ek = e & 15;
                     const int i = isC * 16 + ek, k = i >> 2, r = i & 3;
