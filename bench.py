@@ -332,6 +332,17 @@ def main():
                   "frac": round(valu_insts / avg_s / 1e9 / VALU_PEAK_GINST, 4),
                   "note": "SQ_INSTS_VALU per launch (committed PMC pass) / live launch time; the larger of roofline.frac and "
                           "this one names the bound"}
+        # the same ceiling for the dominant kernel over the launches of the timed region: state updates of the four grouped stage
+        # shapes (two blocks each per step), from the model's sizes
+        dom_short = dom.replace("vivim_", "")
+        ceiling = None
+        if dom_short in VALU_IDEAL:
+            upd = sum(2 * a.train_bs * 3 * (a.expand * d) * (a.clip_length * (a.image_size // st) ** 2) * a.d_state
+                      for d, st in zip((64, 128, 320, 512), (4, 8, 16, 32)))              # per step and rank
+            c = valu_ceiling(dom_short, upd / 8.0, per[dom][0] / per[dom][2])
+            ceiling = {"ceiling_GBps": c["ceiling_GBps"], "frac_of_ceiling": round(ach / c["ceiling_GBps"], 4),
+                       "valu_ideal_us_per_launch": c["ideal_valu_us"], "instr_per_update": c["instr_per_update"],
+                       "note": "min(HBM peak, algorithmic bytes / least VALU issue time): DESIGN.md 4.5"}
         kernels = {k.replace("vivim_", ""): {"launches": v[2], "total_ms": round(v[1] * 1e3, 3),
                                               "avg_us": round(v[1] / v[2] * 1e6, 2),
                                               "alg_GBps": round(v[0] / v[1] / 1e9, 1)} for k, v in per.items()}
@@ -351,7 +362,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom.replace("vivim_", ""), "achieved": round(ach, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                          "traffic": None if stale else traffic, "traffic_unit": "bytes per launch (PMC, separate passes)",
-                         "traffic_source": traffic_src, "traffic_stale": bool(stale), "co_limit": co,
+                         "traffic_source": traffic_src, "traffic_stale": bool(stale), "co_limit": co, "valu_ceiling": ceiling,
                          "algorithmic_bytes_per_launch": int(per[dom][0] / per[dom][2]),
                          "launches": per[dom][2],
                          "avg_launch_us": round(per[dom][1] / per[dom][2] * 1e6, 2),
