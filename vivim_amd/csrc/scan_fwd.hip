@@ -456,7 +456,12 @@ static bool ls_plan(const vivim_ssm_fwd_params& f) {
     const int t = tuning_fwd_variant();
     if (t == 5 || t == 6) return true;
     if (t != 0) return false;
-    return f.dstate == 16 && f.seqlen <= 8192;
+    // Round 3: with the second-generation lanes = states backward (scan_ls2.hip) and the closed-form pre-pass the two backward
+    // families take the same time on long 16-bit rows (cfg 2 grouped stage 0: 547-561 against 555-588 us) while the lanes =
+    // states one moves half the bytes (0.58 against 1.08 GB per launch); the forward pays 20 us there for the denser
+    // checkpoints (262 against 242).  fp32 rows keep the old limit: the denser checkpoints cost the forward 15 % (cfg 3
+    // grouped stage 0: 2974 against 2586 us) for 4 % of the backward.
+    return f.dstate == 16 && f.seqlen <= (f.itype == VIVIM_F32 ? 8192 : 32768);
 }
 int scan_ckpt_len(const vivim_ssm_fwd_params& f) { return ls_plan(f) ? ls_ckpt_len(f) : kChunk; }
 int scan_chunk_len(int) { return kChunk; }
