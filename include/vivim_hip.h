@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define VIVIM_ABI_VERSION 7
+#define VIVIM_ABI_VERSION 8
 
 typedef enum { VIVIM_F32 = 0, VIVIM_F16 = 1, VIVIM_BF16 = 2 } vivim_dtype_t;
 
@@ -242,12 +242,35 @@ typedef struct {
     void *out;                  /* (batch, dim) */
 } vivim_state_update_params;
 
+/* ---- LayerNorm over the channels of a CHANNEL-major token tensor ---------------------------------------
+ * Replaces the ATen calls behind modeling/vivim.py:155-156 (self.norm(x_flat) with x_flat = x.reshape(B, C, L).transpose(-1, -2):
+ * a (B, L, C) view with strides (C*L, 1, L)); the reference has no kernel of its own there.
+ *   forward : y[b][t][c] = (x[b][c][t] - mean[b][t]) * rstd[b][t] * weight[c] + bias[c]      mean / rstd over c, biased variance
+ *   backward: dx[b][c][t] (channel-major like x), dweight[c] += sum dy * xhat, dbias[c] += sum dy   (f32, pre-zeroed by the caller)
+ * x, dx: itype, unit token stride, 16-byte aligned rows, seqlen a whole number of 16-byte pieces; y, dy: otype = VIVIM_F32 (what
+ * autocast makes of layer_norm) or itype, unit channel stride; channels <= 512. */
+typedef struct {
+    int32_t batch, seqlen, channels;
+    int32_t itype, otype;
+    float eps;
+    int64_t x_batch_stride, x_c_stride;      /* x: (batch, channels, seqlen) memory, token stride 1 */
+    int64_t y_batch_stride, y_token_stride;  /* y and dy: (batch, seqlen, channels), channel stride 1 */
+    int64_t dx_batch_stride, dx_c_stride;    /* dx: laid out like x */
+    const void *x;
+    const void *weight, *bias;               /* (channels) f32, or NULL (1 / 0) */
+    void *y;                                 /* forward output */
+    void *mean, *rstd;                       /* (batch, seqlen) f32: written by the forward, read by the backward */
+    const void *dy;                          /* backward input */
+    void *dx;                                /* backward outputs */
+    void *dweight, *dbias;                   /* (channels) f32 pre-zeroed, or NULL */
+} vivim_layernorm_params;
+
 int vivim_abi_version(void);
 const char *vivim_last_error(void);
 
 /* sizeof() of a params struct as this library was compiled, so a foreign-language binding can assert
  * its own layout: which = 0 ssm_fwd, 1 ssm_bwd, 2 conv_fwd, 3 conv_bwd, 4 dwconv, 5 dwconv_wgrad, 6 dir, 7 conv_update,
- * 8 state_update; 0 for anything else. */
+ * 8 state_update, 9 layernorm; 0 for anything else. */
 size_t vivim_sizeof(int which);
 
 /* Tokens per checkpoint row of `x`: n_chunks = ceil(seqlen / vivim_scan_ckpt_len(f)).  Depends on the sizes and flags in
@@ -283,6 +306,8 @@ int vivim_dir_scatter(const vivim_dir_params *p, void *stream);
 int vivim_dir_gather(const vivim_dir_params *p, void *stream);
 int vivim_causal_conv1d_update(const vivim_conv_update_params *p, void *stream);
 int vivim_selective_state_update(const vivim_state_update_params *p, void *stream);
+int vivim_layernorm_cm_fwd(const vivim_layernorm_params *p, void *stream);
+int vivim_layernorm_cm_bwd(const vivim_layernorm_params *p, void *stream);
 
 #ifdef __cplusplus
 }

@@ -28,10 +28,10 @@ def test_struct_layouts_match():
     L = _lib.lib()
     for which, st in enumerate((_lib.SsmFwdParams, _lib.SsmBwdParams, _lib.ConvFwdParams, _lib.ConvBwdParams,
                                 _lib.DwConvParams, _lib.DwConvWgradParams, _lib.DirParams, _lib.ConvUpdateParams,
-                                _lib.StateUpdateParams)):
+                                _lib.StateUpdateParams, _lib.LayerNormParams)):
         assert L.vivim_sizeof(which) == ctypes.sizeof(st)
     assert L.vivim_sizeof(99) == 0
-    assert L.vivim_abi_version() == 7
+    assert L.vivim_abi_version() == 8
     assert L.vivim_scan_chunk_len(_lib.F32) > 0 and L.vivim_scan_chunk_len(_lib.BF16) % 64 == 0
 
 
@@ -47,8 +47,14 @@ def test_checkpoint_length_is_a_function_of_shape_and_tuning():
     prev = L.vivim_set_tuning(0, 0)
     try:
         assert L.vivim_scan_ckpt_len(ctypes.byref(s)) == 16
-        s.seqlen = 20480                                  # long rows: the lanes=tokens backward, long checkpoint rows
+        s.seqlen = 20480                                  # 16-bit rows up to 32768 tokens: still the lanes=states backward (round 3)
         s.u_d_stride = s.delta_d_stride = s.B_dstate_stride = s.C_dstate_stride = 20480
+        assert L.vivim_scan_ckpt_len(ctypes.byref(s)) == 16
+        s.itype = _lib.F32                                # fp32 rows longer than 8192: the lanes=tokens backward, long checkpoint rows
+        assert L.vivim_scan_ckpt_len(ctypes.byref(s)) == L.vivim_scan_chunk_len(_lib.F32)
+        s.itype = _lib.BF16
+        s.seqlen = 40960
+        s.u_d_stride = s.delta_d_stride = s.B_dstate_stride = s.C_dstate_stride = 40960
         assert L.vivim_scan_ckpt_len(ctypes.byref(s)) == long_rows
         L.vivim_set_tuning(0, 6)
         assert L.vivim_scan_ckpt_len(ctypes.byref(s)) == 16

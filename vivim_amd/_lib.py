@@ -105,11 +105,19 @@ class StateUpdateParams(ctypes.Structure):
                 + [(n, vp) for n in ("state", "x", "dt", "A", "B", "C", "D", "z", "dt_bias", "out")])
 
 
+class LayerNormParams(ctypes.Structure):
+    _fields_ = ([(n, i32) for n in ("batch", "seqlen", "channels", "itype", "otype")] + [("eps", ctypes.c_float)]
+                + [(n, i64) for n in ("x_batch_stride", "x_c_stride", "y_batch_stride", "y_token_stride",
+                                      "dx_batch_stride", "dx_c_stride")]
+                + [(n, vp) for n in ("x", "weight", "bias", "y", "mean", "rstd", "dy", "dx", "dweight", "dbias")])
+
+
 EXPORTS = ("vivim_abi_version", "vivim_last_error", "vivim_scan_chunk_len", "vivim_scan_ckpt_len", "vivim_sizeof",
            "vivim_scan_bwd_workspace_bytes", "vivim_scan_fwd_workspace_bytes", "vivim_set_tuning",
            "vivim_selective_scan_fwd", "vivim_selective_scan_bwd",
            "vivim_causal_conv1d_fwd", "vivim_causal_conv1d_bwd", "vivim_dwconv_fwd", "vivim_dwconv_wgrad",
-           "vivim_dir_scatter", "vivim_dir_gather", "vivim_causal_conv1d_update", "vivim_selective_state_update")
+           "vivim_dir_scatter", "vivim_dir_gather", "vivim_causal_conv1d_update", "vivim_selective_state_update",
+           "vivim_layernorm_cm_fwd", "vivim_layernorm_cm_bwd")
 
 _lib = None
 
@@ -146,14 +154,15 @@ def lib():
                          ("vivim_dwconv_fwd", DwConvParams), ("vivim_dwconv_wgrad", DwConvWgradParams),
                          ("vivim_dir_scatter", DirParams), ("vivim_dir_gather", DirParams),
                          ("vivim_causal_conv1d_update", ConvUpdateParams),
-                         ("vivim_selective_state_update", StateUpdateParams)):
+                         ("vivim_selective_state_update", StateUpdateParams),
+                         ("vivim_layernorm_cm_fwd", LayerNormParams), ("vivim_layernorm_cm_bwd", LayerNormParams)):
             fn = getattr(L, name)
             fn.argtypes = [ctypes.POINTER(st), vp]
             fn.restype = ctypes.c_int
-        if L.vivim_abi_version() != 7:
+        if L.vivim_abi_version() != 8:
             raise ImportError("libvivim_hip.so ABI version mismatch")
         for which, st in enumerate((SsmFwdParams, SsmBwdParams, ConvFwdParams, ConvBwdParams, DwConvParams,
-                                    DwConvWgradParams, DirParams, ConvUpdateParams, StateUpdateParams)):
+                                    DwConvWgradParams, DirParams, ConvUpdateParams, StateUpdateParams, LayerNormParams)):
             if L.vivim_sizeof(which) != ctypes.sizeof(st):
                 raise ImportError(f"struct layout mismatch for {st.__name__}: "
                                   f"C {L.vivim_sizeof(which)} vs ctypes {ctypes.sizeof(st)}")

@@ -21,6 +21,7 @@ bool ssm_bwd_dispatch(const vivim_ssm_bwd_params&, hipStream_t);
 int scan_chunk_len(int itype);
 int scan_ckpt_len(const vivim_ssm_fwd_params&);
 size_t scan_bwd_workspace_bytes(const vivim_ssm_fwd_params&);
+bool layernorm_dispatch(const vivim_layernorm_params&, bool bwd, hipStream_t);   // layernorm.hip
 size_t scan_fwd_workspace_bytes(const vivim_ssm_fwd_params&);
 }  // namespace vivim
 
@@ -112,6 +113,7 @@ size_t vivim_sizeof(int which) {
         case 6: return sizeof(vivim_dir_params);
         case 7: return sizeof(vivim_conv_update_params);
         case 8: return sizeof(vivim_state_update_params);
+        case 9: return sizeof(vivim_layernorm_params);
     }
     return 0;
 }
@@ -260,6 +262,36 @@ int vivim_selective_state_update(const vivim_state_update_params* p, void* strea
     VCHECK(p->state && p->x && p->dt && p->A && p->B && p->C && p->out);
     vivim::state_update_launch(*p, static_cast<hipStream_t>(stream));
     return after_launch("selective_state_update");
+}
+
+static int check_layernorm(const vivim_layernorm_params* p) {
+    VCHECK(p != nullptr);
+    VCHECK(dtype_ok(p->itype) && (p->otype == VIVIM_F32 || p->otype == p->itype));
+    VCHECK(p->batch > 0 && p->seqlen > 0 && p->channels > 0 && p->batch <= 65535);
+    if (p->channels > 512)
+        return fail(VIVIM_ERR_UNSUPPORTED, "layernorm_cm: more than 512 channels do not fit the backward's two LDS tiles");
+    const int64_t e = p->itype == VIVIM_F32 ? 4 : 8;             // 16-byte vectors along the tokens of x / dx
+    VCHECK(p->seqlen % e == 0 && p->x_batch_stride % e == 0 && p->x_c_stride % e == 0);
+    VCHECK(p->x && (reinterpret_cast<uintptr_t>(p->x) & 15) == 0 && p->mean && p->rstd);
+    return VIVIM_OK;
+}
+
+int vivim_layernorm_cm_fwd(const vivim_layernorm_params* p, void* stream) {
+    if (int rc = check_layernorm(p)) return rc;
+    VCHECK(p->y != nullptr);
+    if (!vivim::layernorm_dispatch(*p, false, static_cast<hipStream_t>(stream)))
+        return fail(VIVIM_ERR_UNSUPPORTED, "layernorm_cm_fwd not implemented for input type %d / output type %d", p->itype, p->otype);
+    return after_launch("layernorm_cm_fwd");
+}
+
+int vivim_layernorm_cm_bwd(const vivim_layernorm_params* p, void* stream) {
+    if (int rc = check_layernorm(p)) return rc;
+    VCHECK(p->dy && p->dx && (reinterpret_cast<uintptr_t>(p->dx) & 15) == 0);
+    const int64_t e = p->itype == VIVIM_F32 ? 4 : 8;
+    VCHECK(p->dx_batch_stride % e == 0 && p->dx_c_stride % e == 0);
+    if (!vivim::layernorm_dispatch(*p, true, static_cast<hipStream_t>(stream)))
+        return fail(VIVIM_ERR_UNSUPPORTED, "layernorm_cm_bwd not implemented for input type %d / output type %d", p->itype, p->otype);
+    return after_launch("layernorm_cm_bwd");
 }
 
 }  // extern "C"

@@ -33,7 +33,8 @@
 // ~80 % of the time at two waves per SIMD.  What did NOT help, each built, checked and timed (profiles/r03_ls2_experiments.log):
 // two channels of a row side by side in one step for instruction-level parallelism (+5 %), B / C rows read from the
 // staged LDS copy instead of 32 registers (+6 %), the reductions as one block behind the sweep (+1 %), 8-wave workgroups
-// with plain dB / dC stores (+5 ... +18 %), three waves per SIMD with the decays recomputed (spills: not built).  Timing
+// with plain dB / dC stores (+5 ... +18 %), three waves per SIMD (32-token spans, B / C from LDS, 168 VGPRs with spills outside the
+// step loop; tools/experiments/ls2_w3.patch: +8 ... +20 % on 16-bit rows, +1 ... +2 % on fp32).  Timing
 // ablations (LS2_ABL): no LDS reads in the sweeps -11 %, no reductions -15 %, no forward rebuild -14 %, no epilogue -3 %:
 // the cost is spread over the instruction stream, which is what "VALU-bound" looks like from outside.
 #include "ls_common.cuh"

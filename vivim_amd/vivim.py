@@ -27,6 +27,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import dwconv as _dw
+from . import layernorm as _ln
 from .mamba_simple import Mamba
 
 
@@ -140,12 +141,20 @@ class MambaLayer(nn.Module):
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
         self.apply(_init_weights)
 
+    @staticmethod
+    def _norm(norm, x_flat):
+        """nn.LayerNorm's parameters, evaluated by csrc/layernorm.hip when x_flat is the channel-major view built below (the
+        transpose is then the kernel's read pattern instead of a copy in front of ATen's row kernel); ATen otherwise."""
+        if _ln.supported(x_flat, norm.weight) and not os.environ.get("VIVIM_NO_FUSED_LAYERNORM"):
+            return _ln.layer_norm_cm(x_flat, norm.weight, norm.bias, norm.eps)
+        return norm(x_flat)
+
     def forward(self, x):
         B, C, nf, H, W = x.shape
         assert C == self.dim
         x_flat = x.reshape(B, C, nf * H * W).transpose(-1, -2)          # frame-major tokens (vivim.py:151-153)
-        x_flat = x_flat + self.drop_path(self.mamba(self.norm1(x_flat), nframes=nf))
-        x_flat = x_flat + self.drop_path(self.mlp(self.norm2(x_flat), nf, H, W))
+        x_flat = x_flat + self.drop_path(self.mamba(self._norm(self.norm1, x_flat), nframes=nf))
+        x_flat = x_flat + self.drop_path(self.mlp(self._norm(self.norm2, x_flat), nf, H, W))
         return x_flat.transpose(-1, -2).reshape(B, C, nf, H, W)
 
 
