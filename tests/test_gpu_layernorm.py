@@ -26,7 +26,9 @@ def test_layer_norm_channel_major(B, C, L, dtype, autocast, cuda):
     assert ln.supported(x, w)
     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
         y = ln.layer_norm_cm(x, w, b, 1e-5)
-        want_dtype = F.layer_norm(x.detach(), (C,), w.detach(), b.detach(), 1e-5).dtype
+        # ATen: f32 under autocast (layer_norm is on its fp32 list), the input's dtype otherwise (it then wants the weights in
+        # that dtype too; the fused op keeps them f32 either way)
+        want_dtype = F.layer_norm(x.detach(), (C,), w.detach(), b.detach(), 1e-5).dtype if autocast else dtype
     assert y.dtype == want_dtype and y.shape == (B, L, C) and y.is_contiguous()
     g = torch.randn(B, L, C, generator=gen).to(y.dtype).to(cuda)
     y.backward(g)
