@@ -31,26 +31,34 @@ def _params(x, out_dtype, eps):
     return P
 
 
+def _launch(name, P, device):
+    # the step is host-paced: no device context manager when the tensor's device is already the current one (~15 us each)
+    if device.index == torch.cuda.current_device():
+        _lib.call(name, P, torch.cuda.current_stream().cuda_stream)
+    else:
+        with torch.cuda.device(device):
+            _lib.call(name, P, torch.cuda.current_stream().cuda_stream)
+
+
 class _LayerNormCM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, eps, out_dtype):
         B, L, C = x.shape
         y = _lib.empty((B, L, C), out_dtype, x.device)
-        mean = _lib.empty((B, L), torch.float32, x.device)
-        rstd = _lib.empty((B, L), torch.float32, x.device)
+        stats = _lib.empty((2, B, L), torch.float32, x.device)              # mean, rstd
         P = _params(x, out_dtype, eps)
-        P.y_batch_stride, P.y_token_stride = y.stride(0), y.stride(1)
+        P.y_batch_stride, P.y_token_stride = L * C, C
         P.weight, P.bias = weight.data_ptr(), (bias.data_ptr() if bias is not None else None)
-        P.y, P.mean, P.rstd = y.data_ptr(), mean.data_ptr(), rstd.data_ptr()
-        with torch.cuda.device(x.device):
-            _lib.call("vivim_layernorm_cm_fwd", P, torch.cuda.current_stream().cuda_stream)
-        ctx.save_for_backward(x, weight, mean, rstd)
+        P.y, P.mean = y.data_ptr(), stats.data_ptr()
+        P.rstd = P.mean + 4 * B * L
+        _launch("vivim_layernorm_cm_fwd", P, x.device)
+        ctx.save_for_backward(x, weight, stats)
         ctx.eps, ctx.has_bias, ctx.out_dtype = eps, bias is not None, out_dtype
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight, mean, rstd = ctx.saved_tensors
+        x, weight, stats = ctx.saved_tensors
         B, L, C = x.shape
         if dy.dtype != ctx.out_dtype:
             dy = dy.to(ctx.out_dtype)
@@ -58,17 +66,16 @@ class _LayerNormCM(torch.autograd.Function):
             dy = dy.contiguous()
         # dx in x's own layout: (B, C, L) memory seen as (B, L, C)
         dx = _lib.empty((B, C, L), x.dtype, x.device).transpose(1, 2)
-        dweight = _lib.zeros(C, x.device)
-        dbias = _lib.zeros(C, x.device) if ctx.has_bias else None
+        dwb = _lib.zeros(2 * C, x.device)                                    # dweight, dbias: one zero fill
         P = _params(x, ctx.out_dtype, ctx.eps)
         P.y_batch_stride, P.y_token_stride = dy.stride(0), dy.stride(1)
-        P.dx_batch_stride, P.dx_c_stride = dx.stride(0), dx.stride(2)
-        P.weight, P.mean, P.rstd = weight.data_ptr(), mean.data_ptr(), rstd.data_ptr()
-        P.dy, P.dx, P.dweight = dy.data_ptr(), dx.data_ptr(), dweight.data_ptr()
-        P.dbias = dbias.data_ptr() if dbias is not None else None
-        with torch.cuda.device(x.device):
-            _lib.call("vivim_layernorm_cm_bwd", P, torch.cuda.current_stream().cuda_stream)
-        return dx, dweight, dbias, None, None
+        P.dx_batch_stride, P.dx_c_stride = C * L, L
+        P.weight, P.mean = weight.data_ptr(), stats.data_ptr()
+        P.rstd = P.mean + 4 * B * L
+        P.dy, P.dx, P.dweight = dy.data_ptr(), dx.data_ptr(), dwb.data_ptr()
+        P.dbias = P.dweight + 4 * C if ctx.has_bias else None
+        _launch("vivim_layernorm_cm_bwd", P, x.device)
+        return dx, dwb[:C], (dwb[C:] if ctx.has_bias else None), None, None
 
 
 def layer_norm_cm(x, weight, bias, eps=1e-5):
