@@ -90,6 +90,47 @@ def test_conv_vs_oracle(dtype, width, seqlen, cuda, ops):
             assert rel_err(db, rdb) < 1e-4
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("seqlen", [1032, 2048, 4104, 12288])
+@pytest.mark.parametrize("waves", ["1", "48", None])
+def test_conv_pipelined_rows(dtype, seqlen, waves, cuda, ops, monkeypatch):
+    """Aligned rows of two tiles and more take the several-tiles-per-wave kernels (csrc/conv1d.hip, conv1d_*_pipe_kernel):
+    every chain length (VIVIM_CONV_WAVES sets the wave target, hence tiles per wave 1 .. 8), partial last tiles, all widths,
+    Vivim's (L, B*L, 1) layout with dx written into a caller-owned view."""
+    _, cc = ops
+    if waves is None:
+        monkeypatch.delenv("VIVIM_CONV_WAVES", raising=False)
+    else:
+        monkeypatch.setenv("VIVIM_CONV_WAVES", waves)
+    gen = torch.Generator().manual_seed(seqlen + (0 if waves is None else int(waves)))
+    B, D = 2, 40
+    xz = torch.randn(2 * D, B, seqlen, generator=gen).to(dtype).to(cuda).transpose(0, 1)
+    x = xz[:, :D]
+    dout = torch.randn(B, D, seqlen, generator=gen).to(dtype).to(cuda)
+    for width, silu, has_bias in ((4, True, True), (3, True, False), (2, False, True), (4, False, False)):
+        w = torch.randn(D, width, generator=gen).to(cuda)
+        b = torch.randn(D, generator=gen).to(cuda) if has_bias else None
+        out = cc.causal_conv1d_fwd(x, w, b, silu)
+        ref = cpu_oracle.causal_conv1d_fwd(x, w, b, silu)
+        check_close("conv_out", out, _round(ref, dtype), dtype, CONV_CLOSE, _tol(dtype))
+        dxz = torch.full_like(xz, 7.0)
+        dx, dw, db = cc.causal_conv1d_bwd(x, w, b, dout, dxz[:, :D], silu)
+        rdx, rdw, rdb = cpu_oracle.causal_conv1d_bwd(x, w, b, dout, silu)
+        check_close("conv_dx", dx, _round(rdx, dtype), dtype, CONV_CLOSE, _tol(dtype))
+        assert bool((dxz[:, D:] == 7.0).all())
+        assert rel_err(dw, rdw) < 1e-4
+        if has_bias:
+            assert rel_err(db, rdb) < 1e-4
+        else:
+            assert db is None
+    # the one-tile-per-wave kernels on the same problem (the compiler is free to contract the two tap sums differently)
+    monkeypatch.setenv("VIVIM_CONV_NO_PIPE", "1")
+    out1 = cc.causal_conv1d_fwd(x, w, b, silu)
+    dx1, dw1, _ = cc.causal_conv1d_bwd(x, w, b, dout, None, silu)
+    assert rel_err(out1.float(), out.float()) < _tol(dtype) and rel_err(dx1.float(), dx.float()) < _tol(dtype)
+    assert rel_err(dw1, dw) < 1e-5
+
+
 def test_conv_xz_layout_and_prealloc_dx(cuda, ops):
     """The layout Vivim actually passes: x = first half of xz with strides (L, B*L, 1); dx written into a
     caller-owned half of dxz (selective_scan_interface.py:244-245, 281-283)."""

@@ -199,10 +199,208 @@ __global__ void __launch_bounds__(kConvThreads) conv1d_bwd_kernel(const vivim_co
     }
 }
 
+// ---- long aligned rows: several tiles per wave, the next tile's loads in flight under the current tile's arithmetic -----
+// The one-tile-per-wave kernels above finish a tile as load -> arithmetic -> store with nothing of their own to overlap;
+// measured on cfg 2's stage 0 the backward took the SUM of its memory time (26 us at the copy rate) and its instruction
+// time (21 us): waves that start together stay in phase.  Here a wave walks `nt` consecutive tiles of its row and issues
+// tile k+1's loads before it touches tile k.  Halos come from memory as well (4-element vectors either side of the lane's
+// own 16 bytes, L1 hits: the neighbouring lane loads the same line) instead of from lane shuffles, so a lane needs nothing
+// from its neighbours and the edges need no branch: the row is a raw buffer resource of exactly L elements, a vector that
+// starts before the row (wrapped offset) or behind it reads as zeros -- the causal left padding and the tile tail -- and a
+// store behind the row is dropped.  Host-side conditions: 16-byte aligned rows, L a multiple of E.
+using conv_rsrc = __amdgpu_buffer_rsrc_t;
+constexpr unsigned kConvNowhere = 0x80000000u;      // an offset behind every row (rows are < 2 GiB): loads return zeros without traffic
+__device__ __forceinline__ conv_rsrc conv_row(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);
+}
+template <typename T> struct ConvHalo;                      // 4 elements
+template <> struct ConvHalo<float> {
+    using V = u32x4;
+    static __device__ __forceinline__ V load(conv_rsrc r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); }
+};
+template <typename T> struct ConvHalo {
+    using V = u32x2;
+    static __device__ __forceinline__ V load(conv_rsrc r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0); }
+};
+template <typename T, typename V, int N>
+__device__ __forceinline__ void conv_unpack(const V& raw, float* v) {
+    union { V raw; T e[N]; } u;
+    u.raw = raw;
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = to_f32<T>(u.e[j]);
+}
+template <typename T, int E>
+__device__ __forceinline__ void conv_store(conv_rsrc r, unsigned off, const float (&o)[E]) {
+    union { u32x4 raw; T e[E]; } u;
+#pragma unroll
+    for (int k = 0; k < E; ++k) u.e[k] = from_f32<T>(o[k]);
+    __builtin_amdgcn_raw_buffer_store_b128(u.raw, r, off, 0, 0);
+}
+
+template <typename T, bool BWD> struct ConvTile {
+    typename ConvHalo<T>::V xl, xr, dr;      // x[t0-4, t0), x[t0+E, t0+E+4), dout[t0+E, t0+E+4)   (xr, dr: backward only)
+    u32x4 xm, dm;                            // x[t0, t0+E), dout[t0, t0+E)
+};
+template <typename T, int E, bool BWD>
+__device__ __forceinline__ ConvTile<T, BWD> conv_tile_load(conv_rsrc rx, conv_rsrc rd, unsigned off) {
+    ConvTile<T, BWD> t;
+    t.xl = ConvHalo<T>::load(rx, off - 4u * (unsigned)sizeof(T));
+    t.xm = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+    if (BWD) {
+        t.xr = ConvHalo<T>::load(rx, off + 16u);
+        t.dm = __builtin_amdgcn_raw_buffer_load_b128(rd, off, 0, 0);
+        t.dr = ConvHalo<T>::load(rd, off + 16u);
+    }
+    return t;
+}
+
+// The waves of the launch are numbered through (channel, chunk) pairs, a chunk being nt consecutive 64*E-token tiles of the
+// row (blockIdx.z, channel); grid (ceil(dim * cpr / 4), 1, batch).  A wave past the last channel has nothing to do (no barrier).
+__device__ __forceinline__ bool conv_chunk(int dim, int cpr, int& c, int& chunk) {
+    const int wid = blockIdx.x * (kConvThreads / kWave) + (threadIdx.x >> 6);
+    c = __builtin_amdgcn_readfirstlane(wid / cpr);
+    chunk = __builtin_amdgcn_readfirstlane(wid - c * cpr);
+    return c < dim;
+}
+
+template <typename T, typename WT, int E, bool SILU>
+__global__ void __launch_bounds__(kConvThreads) conv1d_fwd_pipe_kernel(const vivim_conv_fwd_params p, const int nt, const int cpr) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.z;
+    int c, chunk;
+    if (!conv_chunk(p.dim, cpr, c, chunk)) return;
+    const unsigned row_bytes = (unsigned)p.seqlen * (unsigned)sizeof(T);
+    const conv_rsrc rx = conv_row(static_cast<const T*>(p.x) + b * p.x_batch_stride + c * p.x_c_stride, row_bytes);
+    const conv_rsrc ro = conv_row(static_cast<T*>(p.out) + b * p.out_batch_stride + c * p.out_c_stride, row_bytes);
+    float w4[4];
+    load_taps<WT>(static_cast<const WT*>(p.weight) + c * p.weight_c_stride, p.weight_width_stride, p.width, w4);
+    const float bias = p.bias ? to_f32<WT>(static_cast<const WT*>(p.bias)[c]) : 0.0f;
+
+    constexpr unsigned kTileBytes = kWave * 16u;
+    unsigned off = (unsigned)(chunk * nt) * kTileBytes + (unsigned)lane * 16u;
+    ConvTile<T, false> cur = conv_tile_load<T, E, false>(rx, rx, off);
+    for (int k = 0; k < nt; ++k, off += kTileBytes) {
+        const ConvTile<T, false> nxt = conv_tile_load<T, E, false>(rx, rx, k + 1 < nt ? off + kTileBytes : kConvNowhere);
+        float X[E + 4];                          // X[i] = x[t0 - 4 + i]
+        conv_unpack<T, typename ConvHalo<T>::V, 4>(cur.xl, X);
+        conv_unpack<T, u32x4, E>(cur.xm, X + 4);
+        float o[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            float acc = bias;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = fmaf(w4[i], X[j + 1 + i], acc);
+            o[j] = SILU ? acc * sigmoidf_fast(acc) : acc;
+        }
+        conv_store<T, E>(ro, off, o);
+        cur = nxt;
+    }
+}
+
+template <typename T, typename WT, int E, bool SILU>
+__global__ void __launch_bounds__(kConvThreads) conv1d_bwd_pipe_kernel(const vivim_conv_bwd_params p, const int nt, const int cpr) {
+    const vivim_conv_fwd_params& f = p.f;
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.z;
+    int c, chunk;
+    if (!conv_chunk(f.dim, cpr, c, chunk)) return;
+    const unsigned row_bytes = (unsigned)f.seqlen * (unsigned)sizeof(T);
+    const conv_rsrc rx = conv_row(static_cast<const T*>(f.x) + b * f.x_batch_stride + c * f.x_c_stride, row_bytes);
+    const conv_rsrc rd = conv_row(static_cast<const T*>(p.dout) + b * p.dout_batch_stride + c * p.dout_c_stride, row_bytes);
+    const conv_rsrc ro = conv_row(static_cast<T*>(p.dx) + b * p.dx_batch_stride + c * p.dx_c_stride, row_bytes);
+    float w4[4];
+    load_taps<WT>(static_cast<const WT*>(f.weight) + c * f.weight_c_stride, f.weight_width_stride, f.width, w4);
+    const float bias = f.bias ? to_f32<WT>(static_cast<const WT*>(f.bias)[c]) : 0.0f;
+
+    constexpr unsigned kTileBytes = kWave * 16u;
+    unsigned off = (unsigned)(chunk * nt) * kTileBytes + (unsigned)lane * 16u;
+    float red[5] = {0.f, 0.f, 0.f, 0.f, 0.f};   // dw4[0..3], dbias over the wave's tiles
+    ConvTile<T, true> cur = conv_tile_load<T, E, true>(rx, rd, off);
+    for (int k = 0; k < nt; ++k, off += kTileBytes) {
+        const ConvTile<T, true> nxt = conv_tile_load<T, E, true>(rx, rd, k + 1 < nt ? off + kTileBytes : kConvNowhere);
+        float X[E + 8];                          // X[i] = x[t0 - 4 + i]
+        float dO[E + 4];                         // dout[t0 + j]
+        conv_unpack<T, typename ConvHalo<T>::V, 4>(cur.xl, X);
+        conv_unpack<T, u32x4, E>(cur.xm, X + 4);
+        conv_unpack<T, typename ConvHalo<T>::V, 4>(cur.xr, X + 4 + E);
+        conv_unpack<T, u32x4, E>(cur.dm, dO);
+        conv_unpack<T, typename ConvHalo<T>::V, 4>(cur.dr, dO + E);
+        float g[E + 3];
+#pragma unroll
+        for (int j = 0; j < E + 3; ++j) {
+            float gj = dO[j];
+            if (SILU) {
+                float pre = bias;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pre = fmaf(w4[i], X[j + 1 + i], pre);
+                const float sg = sigmoidf_fast(pre);
+                gj *= sg * (1.0f + pre * (1.0f - sg));
+            }
+            g[j] = gj;      // tokens >= L carry dout == 0, hence g == 0
+        }
+        float o[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = fmaf(w4[i], g[j + 3 - i], acc);
+            o[j] = acc;
+        }
+        conv_store<T, E>(ro, off, o);
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[i] = fmaf(g[j], X[j + 1 + i], red[i]);
+            red[4] += g[j];
+        }
+        cur = nxt;
+    }
+    float mine = 0.0f;                           // one wave, five atomics (the waves of a workgroup may hold different channels)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const float s = wave_sum(red[i]);
+        if (lane == i) mine = s;
+    }
+    if (lane < 4) {
+        const int src = lane - (4 - f.width);
+        if (src >= 0)
+            atomicAdd(static_cast<float*>(p.dweight) + c * p.dweight_c_stride + src * p.dweight_width_stride, mine);
+    } else if (lane == 4 && p.dbias) {
+        atomicAdd(static_cast<float*>(p.dbias) + c, mine);
+    }
+}
+
+// tiles per wave: enough waves to fill the machine a few times over, chains as long as that allows (VIVIM_CONV_WAVES
+// overrides the wave target for experiments)
+static int conv_pipe_nt(int64_t rows, int tpr) {
+    const char* e = getenv("VIVIM_CONV_WAVES");                  // read per call: tests sweep it
+    const int target = e && atoi(e) > 0 ? atoi(e) : 8192;
+    int nt = (int)std::min<int64_t>(8, std::max<int64_t>(1, rows * tpr / target));
+    const int chunks = (tpr + nt - 1) / nt;
+    return (tpr + chunks - 1) / chunks;
+}
+static bool conv_aligned16(const void* p, int64_t sb, int64_t sc, size_t es) {
+    return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (sb * (int64_t)es) % 16 == 0 && (sc * (int64_t)es) % 16 == 0;
+}
+template <typename T>
+static bool conv_pipe_ok(const vivim_conv_fwd_params& f, int E) {
+    const bool off = getenv("VIVIM_CONV_NO_PIPE") != nullptr;
+    const int tpr = (f.seqlen + kWave * E - 1) / (kWave * E);
+    return !off && f.seqlen % E == 0 && tpr >= 2 && (int64_t)f.seqlen * (int64_t)sizeof(T) < (1ll << 31) &&
+           f.batch <= 65535 && conv_aligned16(f.x, f.x_batch_stride, f.x_c_stride, sizeof(T));
+}
+
 template <typename T, typename WT>
 static void launch_conv_fwd(const vivim_conv_fwd_params& p, hipStream_t stream) {
     constexpr int E = 16 / sizeof(T);   // one 16-byte access per lane
     const int tpr = (p.seqlen + kWave * E - 1) / (kWave * E);          // 64*E-token tiles per row
+    if (conv_pipe_ok<T>(p, E) && conv_aligned16(p.out, p.out_batch_stride, p.out_c_stride, sizeof(T))) {
+        const int nt = conv_pipe_nt((int64_t)p.batch * p.dim, tpr), cpr = (tpr + nt - 1) / nt, wpb = kConvThreads / kWave;
+        const dim3 grid((unsigned)(((int64_t)p.dim * cpr + wpb - 1) / wpb), 1, p.batch);
+        if (p.silu_activation) hipLaunchKernelGGL((conv1d_fwd_pipe_kernel<T, WT, E, true>), grid, dim3(kConvThreads), 0, stream, p, nt, cpr);
+        else hipLaunchKernelGGL((conv1d_fwd_pipe_kernel<T, WT, E, false>), grid, dim3(kConvThreads), 0, stream, p, nt, cpr);
+        return;
+    }
     if (tpr < kConvThreads / kWave) {                                   // short rows: waves numbered through (channel, tile)
         const int waves = p.dim * tpr, wpb = kConvThreads / kWave;
         hipLaunchKernelGGL((conv1d_fwd_kernel<T, WT, E, true>), dim3((waves + wpb - 1) / wpb, 1, p.batch), dim3(kConvThreads), 0, stream, p);
@@ -215,6 +413,14 @@ template <typename T, typename WT>
 static void launch_conv_bwd(const vivim_conv_bwd_params& p, hipStream_t stream) {
     constexpr int E = 16 / sizeof(T);
     const int tpr = (p.f.seqlen + kWave * E - 1) / (kWave * E);
+    if (conv_pipe_ok<T>(p.f, E) && conv_aligned16(p.dout, p.dout_batch_stride, p.dout_c_stride, sizeof(T)) &&
+        conv_aligned16(p.dx, p.dx_batch_stride, p.dx_c_stride, sizeof(T))) {
+        const int nt = conv_pipe_nt((int64_t)p.f.batch * p.f.dim, tpr), cpr = (tpr + nt - 1) / nt, wpb = kConvThreads / kWave;
+        const dim3 grid((unsigned)(((int64_t)p.f.dim * cpr + wpb - 1) / wpb), 1, p.f.batch);
+        if (p.f.silu_activation) hipLaunchKernelGGL((conv1d_bwd_pipe_kernel<T, WT, E, true>), grid, dim3(kConvThreads), 0, stream, p, nt, cpr);
+        else hipLaunchKernelGGL((conv1d_bwd_pipe_kernel<T, WT, E, false>), grid, dim3(kConvThreads), 0, stream, p, nt, cpr);
+        return;
+    }
     if (tpr < kConvThreads / kWave) {
         const int waves = p.f.dim * tpr, wpb = kConvThreads / kWave;
         hipLaunchKernelGGL((conv1d_bwd_kernel<T, WT, E, true>), dim3((waves + wpb - 1) / wpb, 1, p.f.batch), dim3(kConvThreads), 0, stream, p);
