@@ -3,10 +3,14 @@
 // What it computes is what the reference kernels compute (causal-conv1d/csrc/causal_conv1d_fwd.cu:39-130,
 // causal_conv1d_bwd.cu:46-240); how is different: the reference walks one (batch, channel) row per
 // 128-thread block, chunk after chunk, passing halos through shared memory with three barriers per
-// chunk.  Here every wave owns an independent 64*E-token tile of one row (grid = tiles x dim x batch, so
-// a 20480-token row is ten 256-thread blocks in flight instead of one), halos move between neighbouring
-// lanes with wave shuffles, the two lanes at the wave edges fetch theirs with guarded scalar loads, and
-// there is no barrier in the forward at all.  Pure stream: 2*s bytes/token forward, 3*s backward.
+// chunk.  Here a row is cut into independent 64*E-token tiles (E = 16 bytes of elements per lane) and there is no
+// barrier anywhere.  Pure stream: 2*s bytes/token forward, 3*s backward.
+//   * conv1d_{fwd,bwd}_pipe_kernel (second half of the file): 16-byte aligned rows of a multiple of E tokens and at
+//     least two tiles -- every launch of Vivim's stages 0-2.  A wave walks up to eight consecutive tiles with the next
+//     tile's loads in flight under the current tile's arithmetic; halos are loaded, not shuffled.
+//   * conv1d_{fwd,bwd}_kernel: everything else (ragged or unaligned rows, rows of one tile: stage 3's 320 tokens).  One
+//     tile per wave; halos move between neighbouring lanes with wave shuffles, the two lanes at the wave edges fetch
+//     theirs with guarded scalar loads.
 #include "common.cuh"
 
 namespace vivim {
