@@ -246,7 +246,9 @@ typedef struct {
  * Replaces the ATen calls behind modeling/vivim.py:155-156 (self.norm(x_flat) with x_flat = x.reshape(B, C, L).transpose(-1, -2):
  * a (B, L, C) view with strides (C*L, 1, L)); the reference has no kernel of its own there.
  *   forward : y[b][t][c] = (x[b][c][t] - mean[b][t]) * rstd[b][t] * weight[c] + bias[c]      mean / rstd over c, biased variance
- *   backward: dx[b][c][t] (channel-major like x), dweight[c] += sum dy * xhat, dbias[c] += sum dy   (f32, pre-zeroed by the caller)
+ *   backward: dx[b][c][t] (channel-major like x), dweight[c] += sum dy * xhat, dbias[c] += sum dy   (f32, pre-zeroed by the caller;
+ *             the per-tile partial sums go through `workspace`, vivim_layernorm_bwd_workspace_bytes() of it, added up by a
+ *             second small kernel on the same stream: required whenever dweight or dbias is given)
  * x, dx: itype, unit token stride, 16-byte aligned rows, seqlen a whole number of 16-byte pieces; y, dy: otype = VIVIM_F32 (what
  * autocast makes of layer_norm) or itype, unit channel stride; channels <= 512. */
 typedef struct {
@@ -263,6 +265,7 @@ typedef struct {
     const void *dy;                          /* backward input */
     void *dx;                                /* backward outputs */
     void *dweight, *dbias;                   /* (channels) f32 pre-zeroed, or NULL */
+    void *workspace;                         /* backward scratch (see above), 16-byte aligned; contents undefined afterwards */
 } vivim_layernorm_params;
 
 int vivim_abi_version(void);
@@ -308,6 +311,7 @@ int vivim_causal_conv1d_update(const vivim_conv_update_params *p, void *stream);
 int vivim_selective_state_update(const vivim_state_update_params *p, void *stream);
 int vivim_layernorm_cm_fwd(const vivim_layernorm_params *p, void *stream);
 int vivim_layernorm_cm_bwd(const vivim_layernorm_params *p, void *stream);
+size_t vivim_layernorm_bwd_workspace_bytes(const vivim_layernorm_params *p);   /* from batch, seqlen, channels, itype */
 
 #ifdef __cplusplus
 }

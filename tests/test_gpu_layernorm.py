@@ -17,8 +17,15 @@ def _cm(B, C, L, dtype, dev, gen):
 @pytest.mark.parametrize("B,C,L", [(3, 64, 20480), (2, 128, 5120), (2, 320, 1280), (3, 512, 320), (1, 96, 40), (2, 8, 8)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("autocast", [False, True])
-def test_layer_norm_channel_major(B, C, L, dtype, autocast, cuda):
+@pytest.mark.parametrize("tile", [None, "8", "16", "32"])
+def test_layer_norm_channel_major(B, C, L, dtype, autocast, tile, cuda, monkeypatch):
+    """Every tile length of the kernels (VIVIM_LN_TT: tokens per wave; None = the automatic choice; a length that does not fit
+    the shape -- LDS, or 16 tokens of a 16-bit row of 8-element vectors -- falls back to the next one that does)."""
     from vivim_amd import layernorm as ln
+    if tile is None:
+        monkeypatch.delenv("VIVIM_LN_TT", raising=False)
+    else:
+        monkeypatch.setenv("VIVIM_LN_TT", tile)
     gen = torch.Generator().manual_seed(C + L)
     x = _cm(B, C, L, dtype, cuda, gen).requires_grad_(True)
     w = (torch.randn(C, generator=gen) * 0.5 + 1.0).to(cuda).requires_grad_(True)
@@ -61,9 +68,13 @@ def test_mamba_layer_uses_the_fused_norm(cuda, monkeypatch):
     """MambaLayer with and without the fused norm: same output and parameter gradients (the norm's nn.LayerNorm parameters and
     state-dict keys are untouched)."""
     from modeling.vivim import MambaLayer
+    from vivim_amd import layernorm as ln
     torch.manual_seed(5)
     layer = MambaLayer(64).to(cuda)
-    x = torch.randn(2, 64, 3, 8, 8, device=cuda)
+    x = torch.randn(2, 64, 2, 32, 32, device=cuda)          # 4 096 tokens: above layernorm.worthwhile's threshold
+    calls = []
+    real = ln.layer_norm_cm
+    monkeypatch.setattr(ln, "layer_norm_cm", lambda *a: (calls.append(1), real(*a))[1])
 
     def run():
         for p in layer.parameters():
@@ -72,8 +83,11 @@ def test_mamba_layer_uses_the_fused_norm(cuda, monkeypatch):
         y.square().mean().backward()
         return y.detach(), {n: p.grad.clone() for n, p in layer.named_parameters()}
     y1, g1 = run()
+    assert len(calls) == 2                                   # norm1 and norm2 both took the kernel
     monkeypatch.setenv("VIVIM_NO_FUSED_LAYERNORM", "1")
     y2, g2 = run()
+    assert len(calls) == 2
+    assert not ln.worthwhile(torch.empty(3, 320, 512, device=cuda)) and ln.worthwhile(torch.empty(3, 5120, 128, device=cuda))
     assert rel_err(y1, y2) < 1e-5
     for n in g1:
         assert rel_err(g1[n], g2[n]) < 2e-4, n

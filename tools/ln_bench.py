@@ -25,7 +25,10 @@ def timeit(fn, iters=50, warmup=5):
 
 
 dev = torch.device("cuda:0")
+only = [int(a) for a in sys.argv[1:]]            # stages to run (default: all four)
 for st, (C, stride) in enumerate(zip((64, 128, 320, 512), (4, 8, 16, 32))):
+    if only and st not in only:
+        continue
     B, L = 3, 5 * (256 // stride) ** 2
     x = torch.randn(B, C, L, device=dev).transpose(1, 2).requires_grad_(True)
     w, b = torch.ones(C, device=dev, requires_grad=True), torch.zeros(C, device=dev, requires_grad=True)

@@ -109,7 +109,7 @@ class LayerNormParams(ctypes.Structure):
     _fields_ = ([(n, i32) for n in ("batch", "seqlen", "channels", "itype", "otype")] + [("eps", ctypes.c_float)]
                 + [(n, i64) for n in ("x_batch_stride", "x_c_stride", "y_batch_stride", "y_token_stride",
                                       "dx_batch_stride", "dx_c_stride")]
-                + [(n, vp) for n in ("x", "weight", "bias", "y", "mean", "rstd", "dy", "dx", "dweight", "dbias")])
+                + [(n, vp) for n in ("x", "weight", "bias", "y", "mean", "rstd", "dy", "dx", "dweight", "dbias", "workspace")])
 
 
 EXPORTS = ("vivim_abi_version", "vivim_last_error", "vivim_scan_chunk_len", "vivim_scan_ckpt_len", "vivim_sizeof",
@@ -117,7 +117,7 @@ EXPORTS = ("vivim_abi_version", "vivim_last_error", "vivim_scan_chunk_len", "viv
            "vivim_selective_scan_fwd", "vivim_selective_scan_bwd",
            "vivim_causal_conv1d_fwd", "vivim_causal_conv1d_bwd", "vivim_dwconv_fwd", "vivim_dwconv_wgrad",
            "vivim_dir_scatter", "vivim_dir_gather", "vivim_causal_conv1d_update", "vivim_selective_state_update",
-           "vivim_layernorm_cm_fwd", "vivim_layernorm_cm_bwd")
+           "vivim_layernorm_cm_fwd", "vivim_layernorm_cm_bwd", "vivim_layernorm_bwd_workspace_bytes")
 
 _lib = None
 
@@ -159,6 +159,8 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = [ctypes.POINTER(st), vp]
             fn.restype = ctypes.c_int
+        L.vivim_layernorm_bwd_workspace_bytes.argtypes = [ctypes.POINTER(LayerNormParams)]
+        L.vivim_layernorm_bwd_workspace_bytes.restype = ctypes.c_size_t
         if L.vivim_abi_version() != 8:
             raise ImportError("libvivim_hip.so ABI version mismatch")
         for which, st in enumerate((SsmFwdParams, SsmBwdParams, ConvFwdParams, ConvBwdParams, DwConvParams,

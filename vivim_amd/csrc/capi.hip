@@ -22,6 +22,7 @@ int scan_chunk_len(int itype);
 int scan_ckpt_len(const vivim_ssm_fwd_params&);
 size_t scan_bwd_workspace_bytes(const vivim_ssm_fwd_params&);
 bool layernorm_dispatch(const vivim_layernorm_params&, bool bwd, hipStream_t);   // layernorm.hip
+size_t layernorm_bwd_workspace_bytes(const vivim_layernorm_params&);
 size_t scan_fwd_workspace_bytes(const vivim_ssm_fwd_params&);
 }  // namespace vivim
 
@@ -284,11 +285,17 @@ int vivim_layernorm_cm_fwd(const vivim_layernorm_params* p, void* stream) {
     return after_launch("layernorm_cm_fwd");
 }
 
+size_t vivim_layernorm_bwd_workspace_bytes(const vivim_layernorm_params* p) {
+    return p && p->batch > 0 && p->seqlen > 0 && p->channels > 0 ? vivim::layernorm_bwd_workspace_bytes(*p) : 0;
+}
+
 int vivim_layernorm_cm_bwd(const vivim_layernorm_params* p, void* stream) {
     if (int rc = check_layernorm(p)) return rc;
     VCHECK(p->dy && p->dx && (reinterpret_cast<uintptr_t>(p->dx) & 15) == 0);
     const int64_t e = p->itype == VIVIM_F32 ? 4 : 8;
     VCHECK(p->dx_batch_stride % e == 0 && p->dx_c_stride % e == 0);
+    if ((p->dweight || p->dbias) && !p->workspace)
+        return fail(VIVIM_ERR_INVALID, "layernorm_cm_bwd: dweight / dbias need the workspace (vivim_layernorm_bwd_workspace_bytes)");
     if (!vivim::layernorm_dispatch(*p, true, static_cast<hipStream_t>(stream)))
         return fail(VIVIM_ERR_UNSUPPORTED, "layernorm_cm_bwd not implemented for input type %d / output type %d", p->itype, p->otype);
     return after_launch("layernorm_cm_bwd");

@@ -6,6 +6,8 @@ vivim_layernorm_params) -- the two norms around the Mamba call of MambaLayer (mo
 The transpose the ATen path does with a copy kernel in front of its row kernel is the kernel's own read pattern here.
 `supported(x, weight)` says whether the fast path applies; the caller falls back to F.layer_norm otherwise (other layouts:
 the ATen kernel is already the right one for token-major rows)."""
+import ctypes
+
 import torch
 
 from . import _lib
@@ -20,6 +22,14 @@ def supported(x, weight):
     e = 16 // x.element_size()
     return (x.stride(1) == 1 and C <= 512 and L % e == 0 and x.stride(0) % e == 0 and x.stride(2) % e == 0
             and x.data_ptr() % 16 == 0 and x.stride(2) >= L)
+
+
+def worthwhile(x):
+    """Where the fused kernels beat the ATen path on the GPU AND repay the extra host time of a Python autograd node
+    (profiles/r03_layernorm.log): from a few thousand tokens up -- stages 0 and 1 of the 256 x 256 configs (32 us against 184,
+    28 against 75 per norm); at stages 2 and 3 (3 840 and 960 tokens) a tile per wave leaves the chip idle and ATen's row kernels
+    are as fast or faster."""
+    return x.shape[0] * x.shape[1] >= 4096
 
 
 def _params(x, out_dtype, eps):
@@ -74,6 +84,8 @@ class _LayerNormCM(torch.autograd.Function):
         P.rstd = P.mean + 4 * B * L
         P.dy, P.dx, P.dweight = dy.data_ptr(), dx.data_ptr(), dwb.data_ptr()
         P.dbias = P.dweight + 4 * C if ctx.has_bias else None
+        ws = _lib.empty((_lib.lib().vivim_layernorm_bwd_workspace_bytes(ctypes.byref(P)) // 4,), torch.float32, x.device)
+        P.workspace = ws.data_ptr()                                          # per-tile dweight / dbias partial sums
         _launch("vivim_layernorm_cm_bwd", P, x.device)
         return dx, dwb[:C], (dwb[C:] if ctx.has_bias else None), None, None
 

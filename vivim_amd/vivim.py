@@ -144,8 +144,10 @@ class MambaLayer(nn.Module):
     @staticmethod
     def _norm(norm, x_flat):
         """nn.LayerNorm's parameters, evaluated by csrc/layernorm.hip when x_flat is the channel-major view built below (the
-        transpose is then the kernel's read pattern instead of a copy in front of ATen's row kernel); ATen otherwise."""
-        if _ln.supported(x_flat, norm.weight) and not os.environ.get("VIVIM_NO_FUSED_LAYERNORM"):
+        transpose is then the kernel's read pattern instead of a copy in front of ATen's row kernel) and has enough tokens for
+        that to pay (layernorm.worthwhile); ATen otherwise."""
+        if (_ln.supported(x_flat, norm.weight) and _ln.worthwhile(x_flat)
+                and not os.environ.get("VIVIM_NO_FUSED_LAYERNORM")):
             return _ln.layer_norm_cm(x_flat, norm.weight, norm.bias, norm.eps)
         return norm(x_flat)
 
