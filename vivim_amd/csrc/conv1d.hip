@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(kConvThreads) conv1d_fwd_pipe_kernel(const viv
 }
 
 template <typename T, typename WT, int E, bool SILU>
-__global__ void __launch_bounds__(kConvThreads) conv1d_bwd_pipe_kernel(const vivim_conv_bwd_params p, const int nt, const int cpr) {
+__global__ void __launch_bounds__(kConvThreads) conv1d_bwd_pipe_kernel(const vivim_conv_bwd_params p, const int nt, const int cpr, const int share) {
     const vivim_conv_fwd_params& f = p.f;
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.z;
@@ -359,11 +359,22 @@ __global__ void __launch_bounds__(kConvThreads) conv1d_bwd_pipe_kernel(const viv
         }
         cur = nxt;
     }
-    float mine = 0.0f;                           // one wave, five atomics (the waves of a workgroup may hold different channels)
+    // dweight / dbias.  Device-scope float atomics are resolved behind the XCDs' L2s, one cache line at a time: they cost about
+    // 70 ns of kernel time per thousand (one tile per wave, 691 k of them at cfg 2's stage 0: 74 us against 28), so as few as
+    // possible: when the host made the chunks per row a multiple of four (share), the workgroup's four waves hold the same
+    // channel and add up in LDS first.
+    __shared__ float part[kConvThreads / kWave][5];
+    float mine = 0.0f;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
         const float s = wave_sum(red[i]);
         if (lane == i) mine = s;
+    }
+    if (share) {                                 // uniform over the workgroup: all four waves are here (same channel, c < dim)
+        if (lane < 5) part[threadIdx.x >> 6][lane] = mine;
+        __syncthreads();
+        if (threadIdx.x >= 5) return;
+        mine = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
     }
     if (lane < 4) {
         const int src = lane - (4 - f.width);
@@ -374,14 +385,16 @@ __global__ void __launch_bounds__(kConvThreads) conv1d_bwd_pipe_kernel(const viv
     }
 }
 
-// tiles per wave: enough waves to fill the machine a few times over, chains as long as that allows (VIVIM_CONV_WAVES
-// overrides the wave target for experiments)
-static int conv_pipe_nt(int64_t rows, int tpr) {
+// Tiles per wave (nt) and chunks per row (cpr): chains as long as a wave target allows (VIVIM_CONV_WAVES overrides it for
+// experiments; at most 16 tiles), and the chunks per row rounded up to a multiple of four where a row has that many tiles, so
+// that a workgroup's four waves share their channel (the backward's atomics, see the kernel).
+static void conv_pipe_plan(int64_t rows, int tpr, int& nt, int& cpr) {
     const char* e = getenv("VIVIM_CONV_WAVES");                  // read per call: tests sweep it
-    const int target = e && atoi(e) > 0 ? atoi(e) : 8192;
-    int nt = (int)std::min<int64_t>(8, std::max<int64_t>(1, rows * tpr / target));
-    const int chunks = (tpr + nt - 1) / nt;
-    return (tpr + chunks - 1) / chunks;
+    const int target = e && atoi(e) > 0 ? atoi(e) : 4096;
+    const int nt0 = (int)std::min<int64_t>(16, std::max<int64_t>(1, rows * tpr / target));
+    cpr = (tpr + nt0 - 1) / nt0;
+    if (cpr >= 2 && (cpr + 3) / 4 * 4 <= tpr) cpr = (cpr + 3) / 4 * 4;
+    nt = (tpr + cpr - 1) / cpr;
 }
 static bool conv_aligned16(const void* p, int64_t sb, int64_t sc, size_t es) {
     return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (sb * (int64_t)es) % 16 == 0 && (sc * (int64_t)es) % 16 == 0;
@@ -399,7 +412,9 @@ static void launch_conv_fwd(const vivim_conv_fwd_params& p, hipStream_t stream) 
     constexpr int E = 16 / sizeof(T);   // one 16-byte access per lane
     const int tpr = (p.seqlen + kWave * E - 1) / (kWave * E);          // 64*E-token tiles per row
     if (conv_pipe_ok<T>(p, E) && conv_aligned16(p.out, p.out_batch_stride, p.out_c_stride, sizeof(T))) {
-        const int nt = conv_pipe_nt((int64_t)p.batch * p.dim, tpr), cpr = (tpr + nt - 1) / nt, wpb = kConvThreads / kWave;
+        int nt, cpr;
+        conv_pipe_plan((int64_t)p.batch * p.dim, tpr, nt, cpr);
+        const int wpb = kConvThreads / kWave;
         const dim3 grid((unsigned)(((int64_t)p.dim * cpr + wpb - 1) / wpb), 1, p.batch);
         if (p.silu_activation) hipLaunchKernelGGL((conv1d_fwd_pipe_kernel<T, WT, E, true>), grid, dim3(kConvThreads), 0, stream, p, nt, cpr);
         else hipLaunchKernelGGL((conv1d_fwd_pipe_kernel<T, WT, E, false>), grid, dim3(kConvThreads), 0, stream, p, nt, cpr);
@@ -419,10 +434,12 @@ static void launch_conv_bwd(const vivim_conv_bwd_params& p, hipStream_t stream) 
     const int tpr = (p.f.seqlen + kWave * E - 1) / (kWave * E);
     if (conv_pipe_ok<T>(p.f, E) && conv_aligned16(p.dout, p.dout_batch_stride, p.dout_c_stride, sizeof(T)) &&
         conv_aligned16(p.dx, p.dx_batch_stride, p.dx_c_stride, sizeof(T))) {
-        const int nt = conv_pipe_nt((int64_t)p.f.batch * p.f.dim, tpr), cpr = (tpr + nt - 1) / nt, wpb = kConvThreads / kWave;
+        int nt, cpr;
+        conv_pipe_plan((int64_t)p.f.batch * p.f.dim, tpr, nt, cpr);
+        const int wpb = kConvThreads / kWave, share = cpr % wpb == 0;
         const dim3 grid((unsigned)(((int64_t)p.f.dim * cpr + wpb - 1) / wpb), 1, p.f.batch);
-        if (p.f.silu_activation) hipLaunchKernelGGL((conv1d_bwd_pipe_kernel<T, WT, E, true>), grid, dim3(kConvThreads), 0, stream, p, nt, cpr);
-        else hipLaunchKernelGGL((conv1d_bwd_pipe_kernel<T, WT, E, false>), grid, dim3(kConvThreads), 0, stream, p, nt, cpr);
+        if (p.f.silu_activation) hipLaunchKernelGGL((conv1d_bwd_pipe_kernel<T, WT, E, true>), grid, dim3(kConvThreads), 0, stream, p, nt, cpr, share);
+        else hipLaunchKernelGGL((conv1d_bwd_pipe_kernel<T, WT, E, false>), grid, dim3(kConvThreads), 0, stream, p, nt, cpr, share);
         return;
     }
     if (tpr < kConvThreads / kWave) {
