@@ -80,6 +80,19 @@ if __name__ == "__main__" and sys.argv[1] == "--kbench":
             doc["per_config"][cfg] = record(d + "_fetch", d + "_write", d + "_valu" if os.path.isdir(d + "_valu") else "-")
     json.dump(doc, open(sys.argv[3], "w"), indent=1)
     print(json.dumps(doc["per_config"], indent=1))
+elif __name__ == "__main__" and sys.argv[1] == "--mix":
+    # python tools/pmc_bench_traffic.py --mix <scratch dir with mix_{fetch,write,valu} pass directories> <out.json>
+    # The launch mix of the bench step (the four grouped stage shapes of configs[1], every entry point once per stage and
+    # iteration) issued by tools/kbench.py instead of bench.py: counter mode over the whole training step dies inside the
+    # profiler under ATen's LayerNorm backward launch every other run (profiles/r03_pmc_*_profiler_abort.log).
+    d = sys.argv[2]
+    res = record(os.path.join(d, "mix_fetch"), os.path.join(d, "mix_write"),
+                 os.path.join(d, "mix_valu") if os.path.isdir(os.path.join(d, "mix_valu")) else "-")
+    json.dump({"note": "rocprofv3 --pmc passes (raw TCC_EA0 request counters, one set per pass; SQ_INSTS_VALU) over `tools/kbench.py "
+                       "--config 2 --groups 3 --stages 0,1,2,3 --kernels sf,sb,cf,cb`: the launch shapes of `bench.py`'s step "
+                       "(BASELINE configs[1]: four stages, equal weight), per launch; reads doubled (gfx950)",
+               "kernels_sha": kernels_sha(), "per_entry_point": res}, open(sys.argv[3], "w"), indent=1)
+    print(json.dumps(res, indent=1))
 elif __name__ == "__main__":
     (fetch, nf) = read_kib(sys.argv[1])
     (write, nw) = total(sys.argv[2], "WRITE_SIZE")
