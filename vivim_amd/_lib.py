@@ -138,6 +138,10 @@ def lib():
             raise ImportError(
                 f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C vivim_amd/csrc`). vivim_amd has no fallback path.")
+        # torch first: its bundled HIP runtime must be the one this process initialises -- loading the library (and with it
+        # /opt/rocm's libamdhip64) before `import torch` leaves two runtimes in the process and every launch of ours then fails
+        # with "no ROCm-capable device is detected" (seen with build() followed by smoke() in one process)
+        import torch  # noqa: F401
         L = ctypes.CDLL(SO_PATH)
         L.vivim_last_error.restype = ctypes.c_char_p
         L.vivim_sizeof.restype = ctypes.c_size_t
