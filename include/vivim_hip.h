@@ -268,12 +268,28 @@ typedef struct {
     void *workspace;                         /* backward scratch (see above), 16-byte aligned; contents undefined afterwards */
 } vivim_layernorm_params;
 
+/* ---- weight-gradient products of the fused inner op's backward (mamba_ssm/ops/selective_scan_interface.py:273, 276) ------------
+ * out[g][i][j] += sum_t a[g][i][t] * b[g][j][t]: both operands with unit stride along t (the grouped op keeps everything
+ * channel-major), t = every token of every clip.  Replaces the two einsum calls there (ddelta_proj_weight: a = ddelta (d, B*l),
+ * b = x_dbl[:, :R]^T; dx_proj_weight: a = dx_dbl^T, b = conv1d_out (d, B*l)) with a split-k MFMA kernel; f16 / bf16 operands,
+ * f32 accumulation and output (pre-zeroed by the caller: the splits add atomically).  k % 8 == 0, 16-byte aligned rows. */
+typedef struct {
+    int32_t groups, m, n, k;
+    int32_t itype;                              /* VIVIM_F16 or VIVIM_BF16, both operands */
+    int32_t _pad0;
+    int64_t a_group_stride, a_row_stride;       /* elements */
+    int64_t b_group_stride, b_row_stride;
+    int64_t out_group_stride, out_row_stride;   /* out: (groups, m, n) f32, unit stride along n */
+    const void *a, *b;
+    void *out;
+} vivim_wgrad_nt_params;
+
 int vivim_abi_version(void);
 const char *vivim_last_error(void);
 
 /* sizeof() of a params struct as this library was compiled, so a foreign-language binding can assert
  * its own layout: which = 0 ssm_fwd, 1 ssm_bwd, 2 conv_fwd, 3 conv_bwd, 4 dwconv, 5 dwconv_wgrad, 6 dir, 7 conv_update,
- * 8 state_update, 9 layernorm; 0 for anything else. */
+ * 8 state_update, 9 layernorm, 10 wgrad_nt; 0 for anything else. */
 size_t vivim_sizeof(int which);
 
 /* Tokens per checkpoint row of `x`: n_chunks = ceil(seqlen / vivim_scan_ckpt_len(f)).  Depends on the sizes and flags in
@@ -312,6 +328,7 @@ int vivim_selective_state_update(const vivim_state_update_params *p, void *strea
 int vivim_layernorm_cm_fwd(const vivim_layernorm_params *p, void *stream);
 int vivim_layernorm_cm_bwd(const vivim_layernorm_params *p, void *stream);
 size_t vivim_layernorm_bwd_workspace_bytes(const vivim_layernorm_params *p);   /* from batch, seqlen, channels, itype */
+int vivim_wgrad_nt(const vivim_wgrad_nt_params *p, void *stream);
 
 #ifdef __cplusplus
 }

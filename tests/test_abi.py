@@ -28,7 +28,7 @@ def test_struct_layouts_match():
     L = _lib.lib()
     for which, st in enumerate((_lib.SsmFwdParams, _lib.SsmBwdParams, _lib.ConvFwdParams, _lib.ConvBwdParams,
                                 _lib.DwConvParams, _lib.DwConvWgradParams, _lib.DirParams, _lib.ConvUpdateParams,
-                                _lib.StateUpdateParams, _lib.LayerNormParams)):
+                                _lib.StateUpdateParams, _lib.LayerNormParams, _lib.WgradNtParams)):
         assert L.vivim_sizeof(which) == ctypes.sizeof(st)
     assert L.vivim_sizeof(99) == 0
     assert L.vivim_abi_version() == 8

@@ -250,6 +250,42 @@ def test_grouped_directions_match_separate_calls(dtype, cuda, monkeypatch):
         assert rel(res["0"][2][n], res["1"][2][n]) < tol, n
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_grouped_backward_weight_gradients_split_k_kernel(dtype, cuda, monkeypatch):
+    """From 8 192 tokens up the grouped op's backward takes csrc/wgrad.hip for x_proj's and dt_proj's weight gradients
+    (selective_scan_interface.py:273, 276) instead of torch.bmm: same gradients (the kernel keeps f32 where bmm rounds its
+    output to the 16-bit type), everything else unchanged."""
+    from mamba_ssm import Mamba
+    from vivim_amd import wgrad
+    torch.manual_seed(9)
+    m = Mamba(d_model=64, d_state=16, d_conv=4, expand=2, bimamba_type="v3", nframes=4).to(cuda)
+    x = torch.randn(2, 4 * 1024, 64, device=cuda)                    # 8 192 tokens
+    calls = []
+    real = wgrad.wgrad_nt
+    monkeypatch.setattr(wgrad, "wgrad_nt", lambda a, b: (calls.append(a.shape), real(a, b))[1])
+    res = {}
+    for mode in ("", "1"):
+        if mode:
+            monkeypatch.setenv("VIVIM_NO_WGRAD_KERNEL", mode)
+        m.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=dtype):
+            y = m(xi)
+        y.float().square().mean().backward()
+        res[mode] = (xi.grad.clone(), {n: p.grad.float().clone() for n, p in m.named_parameters()})
+    assert len(calls) == 2 and calls[0][2] == 8192                   # the first run took the kernel for both products
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
+    assert rel(res[""][0], res["1"][0]) < 1e-4                        # (dB / dC / dA are atomic sums: runs differ in the last bits)
+    touched = 0
+    for n, g in res["1"][1].items():
+        if "x_proj" in n or "dt_proj.weight" in n or "dt_proj_b.weight" in n or "dt_proj_s.weight" in n:
+            assert rel(res[""][1][n], g) < 6e-3, n                    # bmm's 16-bit output rounding
+            touched += 1
+        else:
+            assert rel(res[""][1][n], g) < 1e-4, n
+    assert touched >= 2
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,D,nf,hw", [(2, 8, 5, 48), (1, 3, 3, 8), (3, 64, 5, 256), (2, 4, 1, 64), (1, 2, 8, 8)])
 def test_direction_maps_bit_exact(dtype, B, D, nf, hw, cuda):

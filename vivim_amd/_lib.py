@@ -112,12 +112,19 @@ class LayerNormParams(ctypes.Structure):
                 + [(n, vp) for n in ("x", "weight", "bias", "y", "mean", "rstd", "dy", "dx", "dweight", "dbias", "workspace")])
 
 
+class WgradNtParams(ctypes.Structure):
+    _fields_ = ([(n, i32) for n in ("groups", "m", "n", "k", "itype", "_pad0")]
+                + [(n, i64) for n in ("a_group_stride", "a_row_stride", "b_group_stride", "b_row_stride",
+                                      "out_group_stride", "out_row_stride")]
+                + [(n, vp) for n in ("a", "b", "out")])
+
+
 EXPORTS = ("vivim_abi_version", "vivim_last_error", "vivim_scan_chunk_len", "vivim_scan_ckpt_len", "vivim_sizeof",
            "vivim_scan_bwd_workspace_bytes", "vivim_scan_fwd_workspace_bytes", "vivim_set_tuning",
            "vivim_selective_scan_fwd", "vivim_selective_scan_bwd",
            "vivim_causal_conv1d_fwd", "vivim_causal_conv1d_bwd", "vivim_dwconv_fwd", "vivim_dwconv_wgrad",
            "vivim_dir_scatter", "vivim_dir_gather", "vivim_causal_conv1d_update", "vivim_selective_state_update",
-           "vivim_layernorm_cm_fwd", "vivim_layernorm_cm_bwd", "vivim_layernorm_bwd_workspace_bytes")
+           "vivim_layernorm_cm_fwd", "vivim_layernorm_cm_bwd", "vivim_layernorm_bwd_workspace_bytes", "vivim_wgrad_nt")
 
 _lib = None
 
@@ -159,7 +166,8 @@ def lib():
                          ("vivim_dir_scatter", DirParams), ("vivim_dir_gather", DirParams),
                          ("vivim_causal_conv1d_update", ConvUpdateParams),
                          ("vivim_selective_state_update", StateUpdateParams),
-                         ("vivim_layernorm_cm_fwd", LayerNormParams), ("vivim_layernorm_cm_bwd", LayerNormParams)):
+                         ("vivim_layernorm_cm_fwd", LayerNormParams), ("vivim_layernorm_cm_bwd", LayerNormParams),
+                         ("vivim_wgrad_nt", WgradNtParams)):
             fn = getattr(L, name)
             fn.argtypes = [ctypes.POINTER(st), vp]
             fn.restype = ctypes.c_int
@@ -168,7 +176,8 @@ def lib():
         if L.vivim_abi_version() != 8:
             raise ImportError("libvivim_hip.so ABI version mismatch")
         for which, st in enumerate((SsmFwdParams, SsmBwdParams, ConvFwdParams, ConvBwdParams, DwConvParams,
-                                    DwConvWgradParams, DirParams, ConvUpdateParams, StateUpdateParams, LayerNormParams)):
+                                    DwConvWgradParams, DirParams, ConvUpdateParams, StateUpdateParams, LayerNormParams,
+                                    WgradNtParams)):
             if L.vivim_sizeof(which) != ctypes.sizeof(st):
                 raise ImportError(f"struct layout mismatch for {st.__name__}: "
                                   f"C {L.vivim_sizeof(which)} vs ctypes {ctypes.sizeof(st)}")

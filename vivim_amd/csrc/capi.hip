@@ -23,6 +23,7 @@ int scan_ckpt_len(const vivim_ssm_fwd_params&);
 size_t scan_bwd_workspace_bytes(const vivim_ssm_fwd_params&);
 bool layernorm_dispatch(const vivim_layernorm_params&, bool bwd, hipStream_t);   // layernorm.hip
 size_t layernorm_bwd_workspace_bytes(const vivim_layernorm_params&);
+bool wgrad_nt_dispatch(const vivim_wgrad_nt_params&, hipStream_t);                 // wgrad.hip
 size_t scan_fwd_workspace_bytes(const vivim_ssm_fwd_params&);
 }  // namespace vivim
 
@@ -115,6 +116,7 @@ size_t vivim_sizeof(int which) {
         case 7: return sizeof(vivim_conv_update_params);
         case 8: return sizeof(vivim_state_update_params);
         case 9: return sizeof(vivim_layernorm_params);
+        case 10: return sizeof(vivim_wgrad_nt_params);
     }
     return 0;
 }
@@ -299,6 +301,21 @@ int vivim_layernorm_cm_bwd(const vivim_layernorm_params* p, void* stream) {
     if (!vivim::layernorm_dispatch(*p, true, static_cast<hipStream_t>(stream)))
         return fail(VIVIM_ERR_UNSUPPORTED, "layernorm_cm_bwd not implemented for input type %d / output type %d", p->itype, p->otype);
     return after_launch("layernorm_cm_bwd");
+}
+
+int vivim_wgrad_nt(const vivim_wgrad_nt_params* p, void* stream) {
+    VCHECK(p != nullptr);
+    VCHECK(p->groups > 0 && p->groups <= 65535 && p->m > 0 && p->n > 0 && p->k > 0);
+    VCHECK(p->a && p->b && p->out);
+    if (p->itype != VIVIM_F16 && p->itype != VIVIM_BF16)
+        return fail(VIVIM_ERR_UNSUPPORTED, "wgrad_nt takes f16 or bf16 operands (type %d given): f32 products stay on the library GEMM", p->itype);
+    VCHECK(p->k % 8 == 0 && p->a_row_stride % 8 == 0 && p->b_row_stride % 8 == 0 && p->a_group_stride % 8 == 0 &&
+           p->b_group_stride % 8 == 0);
+    VCHECK((reinterpret_cast<uintptr_t>(p->a) & 15) == 0 && (reinterpret_cast<uintptr_t>(p->b) & 15) == 0);
+    VCHECK((int64_t)((p->m + 63) / 64) * ((p->n + 15) / 16) <= 65535);
+    if (!vivim::wgrad_nt_dispatch(*p, static_cast<hipStream_t>(stream)))
+        return fail(VIVIM_ERR_UNSUPPORTED, "wgrad_nt not implemented for type %d", p->itype);
+    return after_launch("wgrad_nt");
 }
 
 }  // extern "C"

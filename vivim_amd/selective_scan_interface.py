@@ -10,11 +10,14 @@ The CUDA extension calls are replaced by vivim_amd.selective_scan_cuda / causal_
 kernels behind the C ABI); the GEMMs inside the fused op stay on PyTorch-ROCm (hipBLASLt), as in the
 reference where they are plain torch matmuls (:181-182, :272-277).
 """
+import os
+
 import torch
 import torch.nn.functional as F
 from torch.amp import custom_bwd, custom_fwd
 
 from . import causal_conv1d_cuda, selective_scan_cuda
+from . import wgrad as _wg
 
 
 def _unit_l(t):
@@ -287,8 +290,15 @@ class MambaInnerGroupedFnNoOutProj(torch.autograd.Function):
         dx_dbl4[:, R + N:] = dC.permute(1, 2, 0, 3)
         dx_dbl[:, :R] = torch.bmm(delta_proj_weight.transpose(1, 2), ddelta_g)
         # weight gradients: one GEMM per direction over all clips and tokens (fp32 accumulation inside the GEMM)
-        ddelta_proj_weight = torch.bmm(ddelta_g, x_dbl[:, :R].transpose(1, 2))    # (G, D, R)
-        dx_proj_weight = torch.bmm(dx_dbl, conv_g.transpose(1, 2))                # (G, E, D)
+        # (K = every token of every clip against 4 x 128 or 36 x 128 outputs: the library GEMM puts such a product on two to
+        # four workgroups, 77-100 us each at stage 0; csrc/wgrad.hip splits the token axis instead)
+        x_r = x_dbl[:, :R]
+        if _wg.supported(ddelta_g, x_r) and _wg.supported(dx_dbl, conv_g) and not os.environ.get("VIVIM_NO_WGRAD_KERNEL"):
+            ddelta_proj_weight = _wg.wgrad_nt(ddelta_g, x_r).to(delta_proj_weight.dtype)        # (G, D, R)
+            dx_proj_weight = _wg.wgrad_nt(dx_dbl, conv_g).to(x_proj_weight.dtype)               # (G, E, D)
+        else:
+            ddelta_proj_weight = torch.bmm(ddelta_g, x_r.transpose(1, 2))
+            dx_proj_weight = torch.bmm(dx_dbl, conv_g.transpose(1, 2))
         dconv_g = torch.baddbmm(cm(_channel_major(dconv1d_out), G), x_proj_weight.transpose(1, 2), dx_dbl)
         dconv = dconv_g.view(G * Dm, batch, L).permute(1, 0, 2)
         dx, dconv1d_weight, dconv1d_bias = causal_conv1d_cuda.causal_conv1d_bwd(
