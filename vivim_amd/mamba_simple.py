@@ -133,13 +133,14 @@ class Mamba(nn.Module):
                 owner = self
                 for name in mods:
                     owner = getattr(owner, name)
-                self._fused_where.append((owner, attr, buf, g))
+                # (the row's address, dtype and device are kept as plain values: a `buf[g]` view per check costs microseconds)
+                self._fused_where.append((owner._parameters, attr, buf[g].data_ptr(), buf.dtype, buf.device))
 
     def _fused_params(self):
         """-> [conv_w (3, D, 1, W), conv_b (3, D) | None, x_proj_w (3, R + 2N, D), dt_proj_w (3, D, R), dt_bias (3, D),
         A_log (3, D, N), D (3, D)] with autograd edges to the per-direction Parameters.
-        EVERY fused Parameter is looked up again and compared with its row of the buffer (21 attribute reads and data_ptr()
-        calls per forward): a Parameter that was re-assigned, or whose .data got new storage (`m.A_b_log.data = t`, a partial
+        EVERY fused Parameter is looked up again and compared with its row of the buffer (21 registry reads and data_ptr()
+        calls per forward, about 20 us): a Parameter that was re-assigned, or whose .data got new storage (`m.A_b_log.data = t`, a partial
         load_state_dict(assign=True), a `.to()`), makes the module fuse again instead of training on a buffer that
         state_dict() no longer reports."""
         where = getattr(self, "_fused_where", None)
@@ -147,9 +148,9 @@ class Mamba(nn.Module):
         if ok:
             args = self._fused_args
             k = len(self._fused_live)
-            for i, (owner, attr, buf, g) in enumerate(where):
-                prm = getattr(owner, attr)
-                if prm is not args[k + i] or prm.data_ptr() != buf[g].data_ptr() or prm.dtype != buf.dtype or prm.device != buf.device:
+            for i, (params, attr, ptr, dtype, device) in enumerate(where):
+                prm = params.get(attr)                   # the module's own registry: what getattr(owner, attr) resolves to
+                if prm is not args[k + i] or prm.data_ptr() != ptr or prm.dtype != dtype or prm.device != device:
                     ok = False
                     break
         if not ok:
