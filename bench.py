@@ -267,9 +267,14 @@ def main():
     from vivim_amd.train_step import build_model, make_optimizer, synthetic_batch, train_step
     world, rank, local_rank = dp.dist_env()
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dp.init("nccl", dev)                                       # RCCL over xGMI when WORLD_SIZE > 1
+    # VIVIM_DP_BACKEND=gloo (rehearsal only): several ranks on the GPUs there are -- on a one-GPU box every rank lands on cuda:0
+    # and the gradients are reduced through the host: the whole N > 1 code path (DDP buckets over real device tensors, fused
+    # parameter views, max-over-ranks timing) without an 8-GPU node.  The driver's runs use RCCL.
+    backend = os.environ.get("VIVIM_DP_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    dp.init(backend, dev)                                      # RCCL over xGMI when WORLD_SIZE > 1
     amp = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[a.dtype]
 
     _lib.lib()                                                 # fail loudly if the HIP library is missing
