@@ -186,8 +186,10 @@ __device__ __forceinline__ kparams_t fresh_params() {
     return q;
 }
 
+// (amdgpu_waves_per_eu(2): the f32 / z / 64-state PASS 2 otherwise takes 255 VGPRs + 4 AGPRs = one wave per SIMD; with the
+// bound it fits 253 and the other 22 instantiations compile as before, the 16-state ones register for register)
 template <typename T, int PASS, bool HAS_Z, int NST = kChN>
-__global__ void __launch_bounds__(kChWaves * kWave) __attribute__((amdgpu_num_sgpr(kChSgprLimit)))
+__global__ void __launch_bounds__(kChWaves * kWave) __attribute__((amdgpu_num_sgpr(kChSgprLimit), amdgpu_waves_per_eu(2)))
 ssm_fwd_chan_kernel(const vivim_ssm_fwd_params p, const FwdSeg sg) {
     constexpr int N = NST;                            // 16, or 64 as four chunks of 16 per token (the scalar sets hold one chunk)
     constexpr int NCH = N / 16;
