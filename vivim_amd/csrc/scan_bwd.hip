@@ -389,16 +389,18 @@ __global__ void __launch_bounds__(W * kWave, (K == 4 && W == 4) ? 3 : 2) ssm_bwd
             VIVIM_REC(n, HCK, r) = step > 0 ? xck[(((int64_t)b * f.dim + d[r]) * nck + (step * (TILE / kChunk) - 1)) * N + n] : 0.0f;
         }
         f2 dl[K], w[K], dy[K], S1[K], S2[K], dsum = {0.0f, 0.0f};
+        // (loads are issued unconditionally, from the row's first vector for a lane beyond the row, and zeroed by a select: under
+        // `if (in)` hipcc waits for every outstanding load at each use -- cfg 3: -7 % for the backward, round 3)
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             float df[K], dof[K], uu[K];                 // u is re-read for ddelta at the end of the step: 8 VGPRs less
-            unpack(load_vec<T, K>(uB + d[r] * f.u_d_stride + t0, in), uu);
-            unpack(load_vec<T, K>(dlB + d[r] * f.delta_d_stride + t0, in), df);
-            unpack(load_vec<T, K>(doB + d[r] * p.dout_d_stride + t0, in), dof);
+            unpack(load_vec_always<T, K>(uB + d[r] * f.u_d_stride + t0, in, uB + d[r] * f.u_d_stride), uu);
+            unpack(load_vec_always<T, K>(dlB + d[r] * f.delta_d_stride + t0, in, dlB + d[r] * f.delta_d_stride), df);
+            unpack(load_vec_always<T, K>(doB + d[r] * p.dout_d_stride + t0, in, doB + d[r] * p.dout_d_stride), dof);
             if (HAS_Z) {
                 float zf[K], of[K], dzv[K];
-                unpack(load_vec<T, K>(zB + d[r] * f.z_d_stride + t0, in), zf);
-                unpack(load_vec<T, K>(oB + d[r] * f.out_d_stride + t0, in), of);
+                unpack(load_vec_always<T, K>(zB + d[r] * f.z_d_stride + t0, in, zB + d[r] * f.z_d_stride), zf);
+                unpack(load_vec_always<T, K>(oB + d[r] * f.out_d_stride + t0, in, oB + d[r] * f.out_d_stride), of);
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     const float sg = sigmoidf_fast(zf[k]);
@@ -565,7 +567,7 @@ __global__ void __launch_bounds__(W * kWave, (K == 4 && W == 4) ? 3 : 2) ssm_bwd
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             float duv[K], ddv[K], uu[K];
-            unpack(load_vec<T, K>(uB + d[r] * f.u_d_stride + t0, in), uu);
+            unpack(load_vec_always<T, K>(uB + d[r] * f.u_d_stride + t0, in, uB + d[r] * f.u_d_stride), uu);
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 duv[k] = fmaf(dl[k][r], S1[k][r], Dv[r] * dy[k][r]);
@@ -574,7 +576,7 @@ __global__ void __launch_bounds__(W * kWave, (K == 4 && W == 4) ? 3 : 2) ssm_bwd
             if (f.delta_softplus) {                                           // bwd_kernel.cuh:439-452
                 // sigmoid(raw) is applied for raw <= 20 only (the reference leaves ddelta unscaled above)
                 float df[K];
-                unpack(load_vec<T, K>(dlB + d[r] * f.delta_d_stride + t0, in), df);
+                unpack(load_vec_always<T, K>(dlB + d[r] * f.delta_d_stride + t0, in, dlB + d[r] * f.delta_d_stride), df);
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     const float raw = df[k] + bias[r];
@@ -675,18 +677,40 @@ __global__ void __launch_bounds__(kPreW * kWave) ssm_bwd_prepass_kernel(const vi
     wave_lds_fence();
 
     float base[R] = {0.0f, 0.0f}, dfirst[R] = {0.0f, 0.0f};
+    // The next step's delta / dout / z vectors are requested before this step's arithmetic, unconditionally (a lane beyond the
+    // row or a step beyond the segment reads its row's first vector and gets zeros): loads under `if (in)` made every later
+    // wait a full drain and left each step one exposed memory round trip (round 3).
+    RawK<T, K> ndl[R], ndo[R], nz[R];
+    auto request = [&](int step) __attribute__((always_inline)) {
+        const int t0 = step * TILE + lane * K;
+        const bool in = step < s_hi && t0 < L;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            ndl[r] = load_vec_always<T, K>(dlB + d[r] * f.delta_d_stride + t0, in, dlB + d[r] * f.delta_d_stride);
+            ndo[r] = load_vec_always<T, K>(doB + d[r] * p.dout_d_stride + t0, in, doB + d[r] * p.dout_d_stride);
+            if (HAS_Z) nz[r] = load_vec_always<T, K>(zB + d[r] * f.z_d_stride + t0, in, zB + d[r] * f.z_d_stride);
+        }
+    };
+    // (f32 vectors of 8 tokens: the second set of registers costs a wave per SIMD, cfg 3 was 2 % slower with it: request and use)
+    constexpr bool kAhead = sizeof(T) * K <= 16;
+    if (kAhead) request(s_lo);
     for (int step = s_lo; step < s_hi; ++step) {
         const int t0 = step * TILE + lane * K;
         const bool in = t0 < L;                         // L % K == 0 (host): a lane is all-in or all-out
         float c[R][K], dy[R][K];
+        RawK<T, K> cdl[R], cdo[R], cz[R];
+        if (!kAhead) request(step);
+#pragma unroll
+        for (int r = 0; r < R; ++r) { cdl[r] = ndl[r]; cdo[r] = ndo[r]; if (HAS_Z) cz[r] = nz[r]; }
+        if (kAhead) request(step + 1);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             float df[K];
-            unpack(load_vec<T, K>(dlB + d[r] * f.delta_d_stride + t0, in), df);
-            unpack(load_vec<T, K>(doB + d[r] * p.dout_d_stride + t0, in), dy[r]);
+            unpack(cdl[r], df);
+            unpack(cdo[r], dy[r]);
             if (HAS_Z) {
                 float zf[K];
-                unpack(load_vec<T, K>(zB + d[r] * f.z_d_stride + t0, in), zf);
+                unpack(cz[r], zf);
 #pragma unroll
                 for (int k = 0; k < K; ++k) dy[r][k] *= zf[k] * sigmoidf_fast(zf[k]);
             }
